@@ -1,0 +1,127 @@
+/*
+ * partls.h — C ABI of the MI355X-native Partitioned-LS hot path (libpartls_hip.so, gfx950).
+ *
+ * The reference (/root/reference, pure Julia) has no FFI layer; its boundary is Julia multiple dispatch on
+ *   fit(::Type{Opt}, X, y, P; η, nnlsalg, returnAllSolutions)        src/PartitionedLSOpt.jl:73-74
+ *   fit(::Type{Alt}, X, y, P; η, ϵ, T, nnlsalg, rng)                 src/PartitionedLSAlt.jl:50-51
+ *   fit(::Type{BnB}, X, y, P; η, nnlsalg)                            src/PartitionedLSBnB.jl:30
+ *   predict(α, β, t, P, X) / predict(model, X)                       src/PartitionedLS.jl:132,152
+ * A Julia shim keeps those signatures and `ccall`s the entry points below (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C symbols, plain pointers and sizes; no C++ exception crosses this boundary;
+ *   - matrices are COLUMN-MAJOR (Julia native) with an explicit leading dimension;
+ *   - P is int64 (Julia Int on x64) with entries in {0,1}, M x K;
+ *   - every output buffer is caller-allocated; the library never retains or frees caller memory;
+ *   - every call returns a partls_status; partls_last_error() gives the thread-local message;
+ *   - calls are synchronous (they return after the device work has completed);
+ *   - a context is not thread-safe; distinct contexts may be used from distinct threads.
+ *   - there is NO CPU fallback: without a HIP device every compute entry returns PARTLS_ERR_NO_DEVICE.
+ */
+#ifndef PARTLS_H
+#define PARTLS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PARTLS_OK = 0,
+    PARTLS_ERR_BAD_ARG = 1,        /* null pointer, negative size, ld < rows, K too large ...            */
+    PARTLS_ERR_BAD_PARTITION = 2,  /* P has an entry outside {0,1} (PartitionedLS.jl:292 validity clause) */
+    PARTLS_ERR_NONFINITE = 3,      /* NaN/Inf in X or y                                                   */
+    PARTLS_ERR_NO_DEVICE = 4,      /* no HIP device / device index out of range                           */
+    PARTLS_ERR_HIP = 5,            /* a HIP runtime call failed (message has the hipError string)         */
+    PARTLS_ERR_NOT_CONVERGED = 6,  /* an active-set solve hit its pivot cap                               */
+    PARTLS_ERR_UNSUPPORTED = 7,    /* shape outside what the kernels are built for                        */
+    PARTLS_ERR_STATE = 8           /* staged calls issued out of order                                    */
+} partls_status;
+
+/* flags for the Opt entry points */
+#define PARTLS_OPT_FAITHFUL_INTERCEPT 1u /* enumerate all 2^(K+1) sign vectors incl. the intercept's, as Opt.jl:81,85 does.
+                                            Without it the intercept is left free and 2^K subproblems are solved: the
+                                            optimum (model and objective) is identical, min over the ± pair.             */
+#define PARTLS_OPT_GENERIC_KERNEL     2u /* force the global-memory tableau kernel (testing / cross-check)               */
+
+typedef struct partls_ctx partls_ctx;
+
+int          partls_version(void);                 /* 10000*major + 100*minor + patch */
+const char  *partls_last_error(void);              /* thread-local, never NULL        */
+int          partls_device_count(void);            /* 0 when no HIP device is visible */
+
+partls_status partls_create(int device, partls_ctx **out);
+void          partls_destroy(partls_ctx *ctx);
+
+/* ---- fit(Opt, X, y, P; η, returnAllSolutions)  — replaces Opt.jl:73-104 ----------------------------------------------
+ * X: N x M (ldX >= N), y: N, P: M x K (ldP >= M).  Outputs follow cleanupResult (Opt.jl:34-44):
+ *   alpha[M] (sums to 1 per group), beta[K], *t, *opt = ||Xo w - yo||_2 of the winner (un-squared, incl. the η rows),
+ *   *best_index = the reference's 0-based pattern index b (bit k = sign of group k+1, bit K = intercept sign; in
+ *   free-intercept mode bit K is set from the sign of the fitted intercept).
+ *   all_opt: optional (may be NULL); needs PARTLS_OPT_FAITHFUL_INTERCEPT; 2^(K+1) doubles, all_opt[b] = optval of pattern b
+ *   (Opt.jl:90) computed from the Gram form.  Models of individual patterns: partls_opt_pattern(). */
+partls_status partls_fit_opt(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                             const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
+                             double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt);
+
+/* ---- staged form of the same path (multi-GPU sharding, device-resident inputs, benchmarking) ------------------------
+ * prepare:  builds G = Xo'Xo, c = Xo'y, yy (fp64 MFMA), applies η, scales, lays the tableau out for the sweep.
+ *           x_on_device != 0: X and y are DEVICE pointers (hipMalloc / torch) and stay owned by the caller.
+ * sweep:    enumerates Gray indices [g_begin, g_end) of the 2^K' pattern space (K' = K+1 faithful, K free intercept);
+ *           g_end = -1 means "to the end".  Returns the shard's lexicographic minimum (objective, pattern index) —
+ *           the pair a rank feeds into the all-reduce(min).  all_opt as above (indexed by pattern, not by Gray index).
+ * finish:   solves the given pattern once more on its own, computes opt from the data, normalises (cleanupResult). */
+partls_status partls_opt_prepare(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                                 int x_on_device, const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags);
+partls_status partls_opt_sweep(partls_ctx *ctx, int64_t g_begin, int64_t g_end,
+                               double *best_obj, int64_t *best_pattern, double *all_opt, int64_t *n_unconverged);
+partls_status partls_opt_finish(partls_ctx *ctx, int64_t pattern,
+                                double *alpha, double *beta, double *t, double *opt, int64_t *best_index);
+/* raw NNLS solution of one pattern b (reference indexing, K+1 bits): raw_alpha[M+1] >= 0 as nonneg_lsq returns it at
+ * Opt.jl:89, and its optval (Opt.jl:90).  Needs a prepared context. */
+partls_status partls_opt_pattern(partls_ctx *ctx, int64_t pattern, double *raw_alpha, double *optval);
+/* number of subproblems one full sweep solves (2^K or 2^(K+1)) for the prepared problem */
+int64_t       partls_opt_num_patterns(const partls_ctx *ctx);
+
+/* ---- fit(Alt, X, y, P; η, ϵ, T)  — replaces Alt.jl:50-124 ------------------------------------------------------------
+ * alpha0[M+1], beta0[K+1]: the random initial point the Julia shim draws exactly as Alt.jl:58-66 does.
+ * Outputs as Alt.jl:119: alpha[M], beta[K], *t = β[end]*α[end], *opt, *iters = completed iterations. */
+partls_status partls_fit_alt(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                             const int64_t *P, int64_t K, int64_t ldP, double eta, double eps, int64_t T,
+                             const double *alpha0, const double *beta0,
+                             double *alpha, double *beta, double *t, double *opt, int64_t *iters);
+
+/* ---- fit(BnB, X, y, P; η)  — replaces BnB.jl:30-132 -------------------------------------------------------------------
+ * Outputs as BnB.jl:36-40; *nopen = nodes bounded (search order differs from the reference's DFS, so it is not a
+ * parity quantity). */
+partls_status partls_fit_bnb(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                             const int64_t *P, int64_t K, int64_t ldP, double eta,
+                             double *alpha, double *beta, double *t, double *opt, int64_t *nopen);
+
+/* ---- predict(α, β, t, P, X)  — replaces PartitionedLS.jl:132-134: yhat = X*(P.*α)*β .+ t ------------------------------ */
+partls_status partls_predict(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX,
+                             const int64_t *P, int64_t K, int64_t ldP, const double *alpha, const double *beta, double t,
+                             double *yhat);
+
+/* ---- synthetic inputs of BASELINE.md §4, generated in HBM (bit-identical to oracle_synth on the host) -----------------
+ * dX: device N x D (ld = N), dy: device N; wstar: HOST D doubles (alpha*_j beta*_g(j), from partls_synth_truth). */
+partls_status partls_synth_truth(uint64_t seed, int64_t D, int64_t K, int64_t *P, double *wstar);
+partls_status partls_synth_device(partls_ctx *ctx, uint64_t seed, int64_t N, int64_t D, const double *wstar,
+                                  double *dX, double *dy);
+
+/* ---- measurement: HIP-event timings (ms) of the kernels of the LAST staged/fit call on this context -------------------- */
+typedef enum {
+    PARTLS_T_GRAM = 0,      /* gram_build + slab reduction            */
+    PARTLS_T_PREP = 1,      /* η / scaling / tableau layout           */
+    PARTLS_T_SWEEP = 2,     /* the sign-pattern sweep kernel          */
+    PARTLS_T_FINISH = 3,    /* winner re-solve + residual from data   */
+    PARTLS_T_COUNT = 4
+} partls_timer;
+partls_status partls_get_timing(const partls_ctx *ctx, partls_timer which, double *ms);
+/* debugging / tests: copy the Gram products of the prepared problem to the host: G ((M+2) x (M+2), column-major,
+ * variables ordered [features, intercept, y]), i.e. G, c = G[:, M+1], yy = G[M+1, M+1], after η has been applied. */
+partls_status partls_get_gram(const partls_ctx *ctx, double *G_aug);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

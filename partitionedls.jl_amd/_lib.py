@@ -1,0 +1,70 @@
+"""ctypes binding of include/partls.h (the same symbols the Julia shim `ccall`s)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpartls_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK, ERR_BAD_ARG, ERR_BAD_PARTITION, ERR_NONFINITE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED, ERR_STATE = range(9)
+OPT_FAITHFUL_INTERCEPT = 1
+OPT_GENERIC_KERNEL = 2
+T_GRAM, T_PREP, T_SWEEP, T_FINISH = range(4)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_i64 = C.c_int64
+
+# every symbol include/partls.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("partls_version", C.c_int, []),
+    ("partls_last_error", C.c_char_p, []),
+    ("partls_device_count", C.c_int, []),
+    ("partls_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("partls_destroy", None, [C.c_void_p]),
+    ("partls_fit_opt", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
+                                 C.c_uint32, _dp, _dp, _dp, _dp, _ip, _dp]),
+    ("partls_opt_prepare", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_int, C.c_void_p, _i64, _i64,
+                                     C.c_double, C.c_uint32]),
+    ("partls_opt_sweep", C.c_int, [C.c_void_p, _i64, _i64, _dp, _ip, _dp, _ip]),
+    ("partls_opt_finish", C.c_int, [C.c_void_p, _i64, _dp, _dp, _dp, _dp, _ip]),
+    ("partls_opt_pattern", C.c_int, [C.c_void_p, _i64, _dp, _dp]),
+    ("partls_opt_num_patterns", _i64, [C.c_void_p]),
+    ("partls_fit_alt", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
+                                 C.c_double, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    ("partls_fit_bnb", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
+                                 _dp, _dp, _dp, _dp, _ip]),
+    ("partls_predict", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, _i64, _i64, _dp, _dp, C.c_double, _dp]),
+    ("partls_synth_truth", C.c_int, [C.c_uint64, _i64, _i64, _ip, _dp]),
+    ("partls_synth_device", C.c_int, [C.c_void_p, C.c_uint64, _i64, _i64, _dp, C.c_void_p, C.c_void_p]),
+    ("partls_get_timing", C.c_int, [C.c_void_p, C.c_int, _dp]),
+    ("partls_get_gram", C.c_int, [C.c_void_p, _dp]),
+]
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of libpartls_hip.so (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s", "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+def lib():
+    """Load the HIP library. Fails loudly when it is missing: there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(f"{SO_PATH} is missing: build it with __graft_entry__.build() "
+                              f"(make -C '{CSRC}'); partitionedls.jl_amd has no CPU fallback")
+        l = C.CDLL(SO_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(l, name)           # AttributeError here = header/library mismatch
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib

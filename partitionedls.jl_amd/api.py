@@ -1,0 +1,318 @@
+"""Host-side mirror of the reference's operator interface for the hot path (PartitionedLS.jl:3 exports).
+
+fit(Opt|Alt|BnB, X, y, P; η, ...) / predict keep the reference's names, argument meaning, result tuple
+`(PartLSFitResult, nothing, report)` and error behaviour; the arithmetic runs on the MI355X through the C ABI
+(include/partls.h).  Nothing here computes on the CPU beyond argument marshalling.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+
+
+class PartlsError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"partls status {status}: {msg}")
+        self.status = status
+
+
+class Opt:      # Opt.jl:1
+    """Optimal algorithm: complete enumeration of the sign patterns."""
+
+
+class Alt:      # Alt.jl:3
+    """Alternating optimisation."""
+
+
+class BnB:      # BnB.jl:1
+    """Branch and bound."""
+
+
+@dataclass
+class PartLSFitResult:          # PartitionedLS.jl:29-49
+    α: np.ndarray
+    β: np.ndarray
+    t: float
+    P: np.ndarray
+
+    @property
+    def alpha(self):
+        return self.α
+
+    @property
+    def beta(self):
+        return self.β
+
+
+class Report(dict):
+    """The NamedTuple third element of fit's result: .opt (all), .nopen (BnB), .solutions (Opt, returnAllSolutions)."""
+    __getattr__ = dict.__getitem__
+
+
+def library_path():
+    return L.SO_PATH
+
+
+def build_library(force=False):
+    return L.build(force)
+
+
+def _check(st):
+    if st != L.OK:
+        raise PartlsError(st, L.lib().partls_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class Context:
+    """Thin owner of a partls_ctx (one per device)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(L.lib().partls_create(int(device), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            L.lib().partls_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- staged Opt path -------------------------------------------------------------------------------------------
+    def opt_prepare(self, X, y, P, eta=0.0, flags=0):
+        """X, y: host arrays (float64, any layout; copied F-contiguous)."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        P = np.asfortranarray(P, dtype=np.int64)
+        N, M = X.shape
+        self._shape = (N, M, P.shape[1])
+        _check(L.lib().partls_opt_prepare(self._h, X.ctypes.data, N, M, N, y.ctypes.data, 0, P.ctypes.data, P.shape[1],
+                                          P.shape[0], float(eta), int(flags)))
+
+    def opt_prepare_device(self, dX_ptr, dy_ptr, N, M, ldX, P, eta=0.0, flags=0):
+        """dX_ptr, dy_ptr: raw device addresses (e.g. torch tensor .data_ptr()) that stay owned by the caller."""
+        P = np.asfortranarray(P, dtype=np.int64)
+        self._shape = (N, M, P.shape[1])
+        _check(L.lib().partls_opt_prepare(self._h, C.c_void_p(dX_ptr), N, M, ldX, C.c_void_p(dy_ptr), 1, P.ctypes.data,
+                                          P.shape[1], P.shape[0], float(eta), int(flags)))
+
+    def num_patterns(self):
+        return int(L.lib().partls_opt_num_patterns(self._h))
+
+    def opt_sweep(self, g_begin=0, g_end=-1, want_all=False):
+        bo = C.c_double()
+        bp = C.c_int64()
+        nu = C.c_int64()
+        allopt = np.full(self.num_patterns(), np.nan) if want_all else None
+        _check(L.lib().partls_opt_sweep(self._h, int(g_begin), int(g_end), C.byref(bo), C.byref(bp),
+                                        _dp(allopt) if want_all else None, C.byref(nu)))
+        return bo.value, bp.value, allopt, nu.value
+
+    def opt_finish(self, pattern):
+        N, M, K = self._shape
+        a = np.zeros(M)
+        b = np.zeros(K)
+        t = C.c_double()
+        o = C.c_double()
+        bi = C.c_int64()
+        _check(L.lib().partls_opt_finish(self._h, int(pattern), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(bi)))
+        return a, b, t.value, o.value, bi.value
+
+    def opt_pattern(self, pattern):
+        N, M, K = self._shape
+        ra = np.zeros(M + 1)
+        o = C.c_double()
+        _check(L.lib().partls_opt_pattern(self._h, int(pattern), _dp(ra), C.byref(o)))
+        return ra, o.value
+
+    def timing(self, which):
+        ms = C.c_double()
+        _check(L.lib().partls_get_timing(self._h, int(which), C.byref(ms)))
+        return ms.value
+
+    def gram(self):
+        N, M, K = self._shape
+        G = np.zeros((M + 2, M + 2), order="F")
+        _check(L.lib().partls_get_gram(self._h, _dp(G)))
+        return G
+
+    def synth_device(self, seed, N, D, wstar, dX_ptr, dy_ptr):
+        ws = np.ascontiguousarray(wstar, dtype=np.float64)
+        _check(L.lib().partls_synth_device(self._h, C.c_uint64(seed), N, D, _dp(ws), C.c_void_p(dX_ptr), C.c_void_p(dy_ptr)))
+
+
+def synth_truth(seed, D, K):
+    """Partition matrix and true weights of the BASELINE.md §4 synthetic problem (host side, tiny)."""
+    P = np.zeros((D, K), dtype=np.int64, order="F")
+    ws = np.zeros(D)
+    _check(L.lib().partls_synth_truth(C.c_uint64(seed), D, K, _ip(P), _dp(ws)))
+    return P, ws
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# L2 helpers the reference exports (PartitionedLS.jl:76-81, :108-123) — shape bookkeeping only, kept for API parity
+# ---------------------------------------------------------------------------------------------------------------------
+def homogeneousCoords(X, P):
+    X = np.asarray(X)
+    P = np.asarray(P, dtype=np.int64)
+    Xo = np.hstack([X, np.ones((X.shape[0], 1), dtype=X.dtype)])
+    Po = np.zeros((P.shape[0] + 1, P.shape[1] + 1), dtype=np.int64)
+    Po[:-1, :-1] = P
+    Po[-1, -1] = 1
+    return Xo, Po
+
+
+def regularizeProblem(X, y, P, η):
+    if η == 0:
+        return X, y
+    X = np.asarray(X)
+    rows = [np.sqrt(η) * (np.asarray(P)[:, k] == 1).astype(X.dtype)[None, :] for k in range(np.asarray(P).shape[1])]
+    return np.vstack([X] + rows), np.concatenate([np.asarray(y), np.zeros(len(rows), dtype=X.dtype)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fit / predict
+# ---------------------------------------------------------------------------------------------------------------------
+def _marshal(X, y, P):
+    X = np.asarray(X)
+    y = np.asarray(y)
+    P = np.asarray(P)
+    if X.ndim != 2 or y.ndim != 1:
+        raise TypeError("fit: X must be a matrix and y a vector (MethodError in the reference)")
+    if not (np.issubdtype(X.dtype, np.floating) and np.issubdtype(y.dtype, np.floating)):
+        raise TypeError("fit: X and y must be floating point (X::Array{<:AbstractFloat,2}, Opt.jl:73)")
+    if not np.issubdtype(P.dtype, np.integer) or P.ndim != 2:
+        raise TypeError("fit: P must be an integer matrix (P::Array{Int,2})")
+    if X.shape[0] != y.shape[0] or P.shape[0] != X.shape[1]:
+        raise ValueError("DimensionMismatch: X is %s, y is %s, P is %s" % (X.shape, y.shape, P.shape))
+    # Float32 inputs (test/runtests.jl:123-146) are widened; result fields are abstract floats in the reference
+    return (np.asfortranarray(X, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64),
+            np.asfortranarray(P, dtype=np.int64))
+
+
+class _Solutions:
+    """returnAllSolutions (Opt.jl:99-101): element b is (opt_b, PartLSFitResult_b); models are rebuilt on demand."""
+
+    def __init__(self, ctx, all_opt, P):
+        self._ctx, self._all, self._P = ctx, all_opt, P
+
+    def __len__(self):
+        return len(self._all)
+
+    def __getitem__(self, b):
+        if b < 0:
+            b += len(self)
+        a, bt, t, opt, _ = self._ctx.opt_finish(b)
+        return float(self._all[b]), PartLSFitResult(a, bt, t, self._P)
+
+    def __iter__(self):
+        return (self[b] for b in range(len(self)))
+
+
+def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="nnls", returnAllSolutions=False, rng=None,
+        alpha0=None, beta0=None, device=0, faithful_intercept=False, generic_kernel=False):
+    """fit(::Type{Opt|Alt|BnB}, X, y, P; η, ...) -> (PartLSFitResult, None, Report)   [Opt.jl:73, Alt.jl:50, BnB.jl:30]
+
+    η/eta: regularisation (default 0.0);  Alt: ϵ/eps (1e-6), T (100), rng (None | int seed | numpy Generator) or an
+    explicit starting point alpha0[M+1], beta0[K+1];  Opt: returnAllSolutions.
+    faithful_intercept=True enumerates the reference's 2^(K+1) patterns instead of 2^K with a free intercept
+    (same optimum).  nnlsalg is accepted for signature parity; the device solver is an exact active-set method.
+    """
+    if alg not in (Opt, Alt, BnB):
+        raise TypeError("fit: first argument must be Opt, Alt or BnB")
+    eta_v = 0.0 if (η is None and eta is None) else float(η if η is not None else eta)
+    eps_v = 1e-6 if (ϵ is None and eps is None) else float(ϵ if ϵ is not None else eps)
+    if nnlsalg not in ("nnls", "pivot", "fnnls"):
+        raise ValueError("nnlsalg must be one of :nnls, :pivot, :fnnls")
+    Xf, yf, Pf = _marshal(X, y, P)
+    N, M = Xf.shape
+    K = Pf.shape[1]
+    ctx = default_context(device)
+    lib = L.lib()
+    Pout = np.array(Pf, dtype=np.int64, order="C")
+    if alg is Opt:
+        flags = (L.OPT_FAITHFUL_INTERCEPT if (faithful_intercept or returnAllSolutions) else 0) | \
+                (L.OPT_GENERIC_KERNEL if generic_kernel else 0)
+        ctx.opt_prepare(Xf, yf, Pf, eta_v, flags)
+        bobj, bpat, allopt, unconv = ctx.opt_sweep(0, -1, want_all=returnAllSolutions)
+        if unconv:
+            raise PartlsError(L.ERR_NOT_CONVERGED, f"{unconv} subproblems hit the pivot cap")
+        a, b, t, opt, bi = ctx.opt_finish(bpat)
+        model = PartLSFitResult(a, b, t, Pout)
+        if returnAllSolutions:
+            return model, None, Report(solutions=_Solutions(ctx, allopt, Pout))
+        return model, None, Report(opt=opt, best_index=bi)
+    if alg is Alt:
+        if alpha0 is None or beta0 is None:
+            if rng is None:
+                gen = np.random.default_rng()
+            elif isinstance(rng, (int, np.integer)):
+                gen = np.random.default_rng(int(rng))
+            else:
+                gen = rng
+            alpha0 = gen.random(M + 1)                    # Alt.jl:65
+            beta0 = (gen.random(K + 1) - 0.5) * 10        # Alt.jl:66
+        a0 = np.ascontiguousarray(alpha0, dtype=np.float64)
+        b0 = np.ascontiguousarray(beta0, dtype=np.float64)
+        if a0.shape != (M + 1,) or b0.shape != (K + 1,):
+            raise ValueError("alpha0 must have M+1 and beta0 K+1 entries")
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double(); it = C.c_int64()
+        _check(lib.partls_fit_alt(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v, eps_v,
+                                  int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(it)))
+        return PartLSFitResult(a, b, t.value, Pout), None, Report(opt=o.value, iters=it.value)
+    if alg is BnB:
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double(); no = C.c_int64()
+        _check(lib.partls_fit_bnb(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v,
+                                  _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
+        return PartLSFitResult(a, b, t.value, Pout), None, Report(opt=o.value, nopen=no.value)
+    raise TypeError("fit: first argument must be Opt, Alt or BnB")
+
+
+def predict(*args, device=0):
+    """predict(model, X) or predict(α, β, t, P, X)  ->  X * (P .* α) * β .+ t     [PartitionedLS.jl:132-134,152-155]"""
+    if len(args) == 2:
+        model, X = args
+        α, β, t, P = model.α, model.β, model.t, model.P
+    elif len(args) == 5:
+        α, β, t, P, X = args
+    else:
+        raise TypeError("predict(model, X) or predict(α, β, t, P, X)")
+    X = np.asarray(X)
+    if not np.issubdtype(X.dtype, np.floating) or X.ndim != 2:
+        raise TypeError("predict: X must be a floating-point matrix")
+    Xf = np.asfortranarray(X, dtype=np.float64)
+    Pf = np.asfortranarray(P, dtype=np.int64)
+    a = np.ascontiguousarray(α, dtype=np.float64)
+    b = np.ascontiguousarray(β, dtype=np.float64)
+    N, M = Xf.shape
+    if Pf.shape[0] != M or a.shape != (M,) or b.shape != (Pf.shape[1],):
+        raise ValueError("DimensionMismatch in predict")
+    yh = np.zeros(N)
+    ctx = default_context(device)
+    _check(L.lib().partls_predict(ctx._h, Xf.ctypes.data, N, M, N, Pf.ctypes.data, Pf.shape[1], M, _dp(a), _dp(b),
+                                  float(t), _dp(yh)))
+    return yh

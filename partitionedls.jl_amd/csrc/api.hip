@@ -1,0 +1,587 @@
+// api.hip — the C ABI of include/partls.h: host orchestration of the HIP kernels.  No CPU fallback: every compute
+// entry needs a HIP device and fails with PARTLS_ERR_NO_DEVICE / PARTLS_ERR_HIP otherwise.
+#include "common.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <new>
+
+namespace partls {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t b)
+    {
+        if (b <= bytes && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, b ? b : 8);
+        if (e == hipSuccess) bytes = b;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace partls
+
+using namespace partls;
+
+struct partls_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0[PARTLS_T_COUNT] = {}, ev1[PARTLS_T_COUNT] = {};
+    bool timed[PARTLS_T_COUNT] = {};
+    double ms[PARTLS_T_COUNT] = {};
+
+    // problem
+    bool prepared = false;
+    int64_t N = 0, M = 0, K = 0, ldX = 0;
+    double eta = 0.0;
+    uint32_t flags = 0;
+    bool faithful = false;
+    const double *dX = nullptr, *dy = nullptr;     // device views (owned copies below, or the caller's)
+    DevBuf ownX, ownY;
+    std::vector<int64_t> P;                        // M x K compact
+    std::vector<uint64_t> mask_aug;                // M + 2
+    // gram
+    int ldg = 0, chunks = 0;
+    DevBuf slab, G, maskd, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt, sol, wdev, partial, flag,
+        freeVar, maskTmp;
+    std::vector<double> hG, hScale;
+    // tableau
+    int n = 0, kbits = 0, T = 0;
+    bool use_reg = false;
+    double tol = 0.0;
+    unsigned long long last_pivots = 0;
+};
+
+static inline void t_begin(partls_ctx *c, int w) { (void)hipEventRecord(c->ev0[w], c->stream); }
+static inline void t_end(partls_ctx *c, int w) { (void)hipEventRecord(c->ev1[w], c->stream); c->timed[w] = true; }
+static void t_collect(partls_ctx *c)
+{
+    for (int w = 0; w < PARTLS_T_COUNT; ++w)
+        if (c->timed[w]) {
+            float f = 0.f;
+            if (hipEventElapsedTime(&f, c->ev0[w], c->ev1[w]) == hipSuccess) c->ms[w] = (double)f;
+            c->timed[w] = false;
+        }
+}
+
+extern "C" {
+
+int partls_version(void) { return 100; }
+const char *partls_last_error(void) { return g_err; }
+
+int partls_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+partls_status partls_create(int device, partls_ctx **out)
+{
+    if (!out) { set_error("partls_create: out is NULL"); return PARTLS_ERR_BAD_ARG; }
+    *out = nullptr;
+    int n = partls_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        set_error("partls_create: no usable HIP device (count=%d, requested=%d); this library has no CPU fallback", n, device);
+        return PARTLS_ERR_NO_DEVICE;
+    }
+    PARTLS_HIP_CHECK(hipSetDevice(device));
+    partls_ctx *c = new (std::nothrow) partls_ctx();
+    if (!c) { set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+    c->device = device;
+    PARTLS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int w = 0; w < PARTLS_T_COUNT; ++w) {
+        PARTLS_HIP_CHECK(hipEventCreate(&c->ev0[w]));
+        PARTLS_HIP_CHECK(hipEventCreate(&c->ev1[w]));
+    }
+    *out = c;
+    return PARTLS_OK;
+}
+
+void partls_destroy(partls_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskd, &c->scale, &c->Tfull, &c->T0reg, &c->scratch,
+                      &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->sol, &c->wdev, &c->partial, &c->flag,
+                      &c->freeVar, &c->maskTmp};
+    for (DevBuf *b : bufs) b->release();
+    for (int w = 0; w < PARTLS_T_COUNT; ++w) { (void)hipEventDestroy(c->ev0[w]); (void)hipEventDestroy(c->ev1[w]); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------------------------------
+static partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, int64_t ldX, const void *P, int64_t K,
+                                  int64_t ldP)
+{
+    if (!c) { set_error("context is NULL"); return PARTLS_ERR_BAD_ARG; }
+    if (!X || !P) { set_error("X or P is NULL"); return PARTLS_ERR_BAD_ARG; }
+    if (N < 1 || M < 1 || K < 1) { set_error("need N, M, K >= 1 (got %lld, %lld, %lld)", (long long)N, (long long)M, (long long)K); return PARTLS_ERR_BAD_ARG; }
+    if (ldX < N || ldP < M) { set_error("leading dimension smaller than the row count"); return PARTLS_ERR_BAD_ARG; }
+    if (K > 39) { set_error("K = %lld groups: 2^(K+1) sign patterns is out of range (K <= 39)", (long long)K); return PARTLS_ERR_UNSUPPORTED; }
+    if (M + 1 > 1023) { set_error("M = %lld features: this build supports M <= 1022", (long long)M); return PARTLS_ERR_UNSUPPORTED; }
+    return PARTLS_OK;
+}
+
+static partls_status load_partition(partls_ctx *c, const int64_t *P, int64_t M, int64_t K, int64_t ldP)
+{
+    c->P.assign((size_t)M * K, 0);
+    c->mask_aug.assign((size_t)M + 2, 0);
+    for (int64_t k = 0; k < K; ++k)
+        for (int64_t m = 0; m < M; ++m) {
+            const int64_t v = P[m + k * ldP];
+            if (v != 0 && v != 1) { set_error("P[%lld,%lld] = %lld is not 0/1", (long long)m, (long long)k, (long long)v); return PARTLS_ERR_BAD_PARTITION; }
+            c->P[(size_t)m + (size_t)k * M] = v;
+            if (v) c->mask_aug[(size_t)m] |= (1ULL << k);
+        }
+    c->mask_aug[(size_t)M] = 1ULL << K;            // the intercept's own group (homogeneousCoords, PartitionedLS.jl:78)
+    c->mask_aug[(size_t)M + 1] = 0;                // y
+    return PARTLS_OK;
+}
+
+// regularised augmented Gram entry on the host copy (mirrors reg_entry in misc.hip)
+static double h_reg(const partls_ctx *c, int a, int b)
+{
+    double v = c->hG[(size_t)a * c->ldg + b];
+    if (c->eta != 0.0 && a <= c->M && b <= c->M) v += c->eta * (double)__builtin_popcountll(c->mask_aug[a] & c->mask_aug[b]);
+    return v;
+}
+
+static uint64_t gray_inverse(uint64_t pat)
+{
+    uint64_t g = pat;
+    for (int s = 1; s < 64; s <<= 1) g ^= g >> s;
+    return g;
+}
+
+// Solve ONE pattern with the global-memory kernel and fetch the scaled solution.  mask_dev/free_dev may override the
+// prepared masks (Alt zero-β groups, BnB free groups).  Tableau must be prepared.
+static partls_status solve_single(partls_ctx *c, uint64_t pattern, const uint64_t *mask_dev, const uint8_t *free_dev,
+                                  std::vector<double> &sol, double *obj2, unsigned long long *unconv)
+{
+    const int n = c->n, ld = n + 1;
+    PARTLS_HIP_CHECK(c->scratch.ensure((size_t)ld * ld * sizeof(double)));
+    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
+    PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
+    PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
+    PARTLS_HIP_CHECK(c->sol.ensure((size_t)(n + 1) * sizeof(double)));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    SweepParams p{};
+    p.n = n; p.kbits = c->kbits;
+    p.mask = mask_dev ? mask_dev : c->maskd.as<uint64_t>();
+    p.T0 = c->Tfull.as<double>();
+    p.scratch = c->scratch.as<double>();
+    const uint64_t g = gray_inverse(pattern);
+    p.g_begin = (int64_t)g; p.g_end = (int64_t)g + 1; p.chain_len = 1;
+    p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
+    p.all_opt = nullptr;
+    p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
+    p.n_unconverged = c->counters.as<unsigned long long>();
+    p.n_pivots = c->counters.as<unsigned long long>() + 1;
+    p.sol = c->sol.as<double>(); p.sol_obj2 = c->sol.as<double>() + n;
+    p.free_var = free_dev;
+    PARTLS_HIP_CHECK(launch_sweep_generic(p, 1, c->stream));
+    sol.resize((size_t)n + 1);
+    unsigned long long cnt[2] = {0, 0};
+    PARTLS_HIP_CHECK(hipMemcpyAsync(sol.data(), c->sol.p, (size_t)(n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (obj2) *obj2 = sol[(size_t)n];
+    if (unconv) *unconv = cnt[0];
+    return PARTLS_OK;
+}
+
+// scaled tableau solution -> w over [features, intercept] (length M+1), using the host Gram copy for a free intercept
+static void unscale_solution(const partls_ctx *c, const std::vector<double> &sol, std::vector<double> &w)
+{
+    const int M = (int)c->M;
+    w.assign((size_t)M + 1, 0.0);
+    for (int i = 0; i < c->n; ++i) w[(size_t)i] = sol[(size_t)i] * c->hScale[(size_t)i];
+    if (!c->faithful) {
+        // intercept eliminated up front: t = (c_I - sum_f G_If w_f) / G_II   (row I of the normal equations)
+        double s = h_reg(c, M, M + 1);
+        for (int f = 0; f < M; ++f) s -= h_reg(c, M, f) * w[(size_t)f];
+        w[(size_t)M] = s / h_reg(c, M, M);
+    }
+}
+
+// ||Xo w - yo||_2 from the data (+ the η rows): Opt.jl:90
+static partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt)
+{
+    const int64_t M = c->M;
+    const int nb = 1024;
+    PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
+    PARTLS_HIP_CHECK(c->partial.ensure(nb * sizeof(double)));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(launch_residual(c->dX, c->N, M, c->ldX, c->dy, c->wdev.as<double>(), w[(size_t)M],
+                                     c->partial.as<double>(), nb, nullptr, c->stream));
+    std::vector<double> part((size_t)nb);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(part.data(), c->partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(size_t)b];
+    if (c->eta != 0.0) {
+        for (int64_t k = 0; k <= c->K; ++k) {           // the K' regularisation rows: sqrt(eta) * sum_{m in group k} w_m
+            double g = 0.0;
+            for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) g += w[(size_t)m];
+            s += c->eta * g * g;
+        }
+    }
+    *opt = std::sqrt(s);
+    return PARTLS_OK;
+}
+
+// cleanupResult (Opt.jl:34-44) from w = f∘α: raw α_m = w_m / f_m, raw β_k = s_k
+static void cleanup_opt(const partls_ctx *c, const std::vector<double> &w, uint64_t pattern, double *alpha, double *beta, double *t)
+{
+    const int64_t M = c->M, K = c->K;
+    std::vector<double> a((size_t)M, 0.0);
+    for (int64_t m = 0; m < M; ++m) {
+        const int f = 2 * __builtin_popcountll(c->mask_aug[(size_t)m] & pattern) - __builtin_popcountll(c->mask_aug[(size_t)m]);
+        a[(size_t)m] = (f != 0) ? w[(size_t)m] / (double)f : 0.0;
+        if (a[(size_t)m] < 0.0) a[(size_t)m] = 0.0;      // round-off guard: nonneg_lsq never returns negatives
+    }
+    std::vector<double> A((size_t)K, 0.0);
+    for (int64_t k = 0; k < K; ++k) {
+        double s = 0.0;
+        for (int64_t m = 0; m < M; ++m) s += (double)c->P[(size_t)m + (size_t)k * M] * a[(size_t)m];
+        const double sk = ((pattern >> k) & 1ULL) ? 1.0 : -1.0;
+        beta[k] = sk * s;
+        A[(size_t)k] = (s == 0.0) ? 1.0 : s;
+    }
+    for (int64_t m = 0; m < M; ++m) {
+        double s = 0.0;
+        for (int64_t k = 0; k < K; ++k) s += (double)c->P[(size_t)m + (size_t)k * M] * a[(size_t)m] / A[(size_t)k];
+        alpha[m] = s;
+    }
+    *t = w[(size_t)M];                                   // t = β[end]*α[end] = f_I α_I = w_I (Opt.jl:92)
+}
+
+extern "C" {
+
+partls_status partls_opt_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                                 int x_on_device, const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags)
+{
+    partls_status st = check_common(c, X, N, M, ldX, P, K, ldP);
+    if (st != PARTLS_OK) return st;
+    if (!y) { set_error("y is NULL"); return PARTLS_ERR_BAD_ARG; }
+    if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
+    c->prepared = false;
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    st = load_partition(c, P, M, K, ldP);
+    if (st != PARTLS_OK) return st;
+    c->N = N; c->M = M; c->K = K; c->eta = eta; c->flags = flags;
+    c->faithful = (flags & PARTLS_OPT_FAITHFUL_INTERCEPT) != 0;
+
+    if (x_on_device) {
+        c->dX = X; c->dy = y; c->ldX = ldX;
+    } else {
+        PARTLS_HIP_CHECK(c->ownX.ensure((size_t)N * M * sizeof(double)));
+        PARTLS_HIP_CHECK(c->ownY.ensure((size_t)N * sizeof(double)));
+        PARTLS_HIP_CHECK(hipMemcpy2DAsync(c->ownX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double),
+                                          (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->ownY.p, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->dX = c->ownX.as<double>(); c->dy = c->ownY.as<double>(); c->ldX = N;
+    }
+    // NaN / Inf screen
+    PARTLS_HIP_CHECK(c->flag.ensure(sizeof(int)));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->flag.p, 0, sizeof(int), c->stream));
+    PARTLS_HIP_CHECK(launch_finite_check(c->dX, N, M, c->ldX, c->dy, c->flag.as<int>(), c->stream));
+
+    // Gram products
+    const size_t slabd = gram_slab_doubles(N, M, &c->chunks, &c->ldg);
+    PARTLS_HIP_CHECK(c->slab.ensure(slabd * sizeof(double)));
+    PARTLS_HIP_CHECK(c->G.ensure((size_t)c->ldg * c->ldg * sizeof(double)));
+    t_begin(c, PARTLS_T_GRAM);
+    PARTLS_HIP_CHECK(launch_gram(c->dX, N, M, c->ldX, c->dy, c->slab.as<double>(), c->chunks, c->ldg, c->G.as<double>(), c->stream));
+    t_end(c, PARTLS_T_GRAM);
+
+    // tableau
+    c->n = c->faithful ? (int)M + 1 : (int)M;
+    c->kbits = c->faithful ? (int)K + 1 : (int)K;
+    PARTLS_HIP_CHECK(c->maskd.ensure(((size_t)M + 2) * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskd.p, c->mask_aug.data(), ((size_t)M + 2) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(c->scale.ensure((size_t)c->n * sizeof(double)));
+    PARTLS_HIP_CHECK(c->Tfull.ensure((size_t)(c->n + 1) * (c->n + 1) * sizeof(double)));
+    t_begin(c, PARTLS_T_PREP);
+    PARTLS_HIP_CHECK(launch_prep(c->G.as<double>(), c->ldg, (int)M, eta, c->maskd.as<uint64_t>(), c->faithful ? 0 : 1,
+                                 c->scale.as<double>(), c->Tfull.as<double>(), c->n, c->stream));
+    c->use_reg = sweep_reg_supported(c->n) && !(flags & PARTLS_OPT_GENERIC_KERNEL);
+    if (c->use_reg) {
+        c->T = sweep_reg_tiles(c->n);
+        PARTLS_HIP_CHECK(c->T0reg.ensure(sweep_reg_t0_doubles(c->T) * sizeof(double)));
+        PARTLS_HIP_CHECK(launch_layout_reg(c->Tfull.as<double>(), c->n, c->T, c->T0reg.as<double>(), c->stream));
+    }
+    t_end(c, PARTLS_T_PREP);
+
+    c->hG.resize((size_t)c->ldg * c->ldg);
+    c->hScale.resize((size_t)c->n);
+    int bad = 0;
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->hG.data(), c->G.p, c->hG.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->hScale.data(), c->scale.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(&bad, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    t_collect(c);
+    if (bad) { set_error("X or y contains NaN/Inf"); return PARTLS_ERR_NONFINITE; }
+    const double yy = c->hG[(size_t)(M + 1) * c->ldg + (M + 1)];
+    const char *tolenv = getenv("PARTLS_TOL_REL");
+    const double tolrel = tolenv ? atof(tolenv) : 1e-11;
+    c->tol = tolrel * std::sqrt(yy > 0.0 ? yy : 0.0);
+    if (!(c->tol > 0.0)) c->tol = 1e-300;
+    c->prepared = true;
+    return PARTLS_OK;
+}
+
+int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared) ? ((int64_t)1 << c->kbits) : 0; }
+
+partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, double *best_obj, int64_t *best_pattern,
+                               double *all_opt, int64_t *n_unconverged)
+{
+    if (!c || !c->prepared) { set_error("partls_opt_sweep: context not prepared"); return PARTLS_ERR_STATE; }
+    const int64_t npat = (int64_t)1 << c->kbits;
+    if (g_end < 0) g_end = npat;
+    if (g_begin < 0 || g_begin > g_end || g_end > npat) { set_error("bad Gray-index range [%lld,%lld)", (long long)g_begin, (long long)g_end); return PARTLS_ERR_BAD_ARG; }
+    if (all_opt && !c->faithful) { set_error("all_opt needs PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    if (g_begin == g_end) {
+        if (best_obj) *best_obj = INFINITY;
+        if (best_pattern) *best_pattern = -1;
+        if (n_unconverged) *n_unconverged = 0;
+        return PARTLS_OK;
+    }
+    const int n = c->n, ld = n + 1;
+    const int64_t total = g_end - g_begin;
+    const char *cl = getenv("PARTLS_CHAIN_LEN");
+    int64_t chain_len = cl ? atoll(cl) : (c->use_reg ? 512 : 64);
+    if (chain_len < 1) chain_len = 1;
+    // keep every CU busy on small problems: at least ~2 chains per CU when there are enough patterns
+    while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
+    const int64_t nchains = (total + chain_len - 1) / chain_len;
+    const char *ge = getenv("PARTLS_GRID");
+    int grid = (int)std::min<int64_t>(nchains, ge ? atoll(ge) : (c->use_reg ? 4096 : 1024));
+    if (grid < 1) grid = 1;
+
+    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * std::max(grid, 4096)));
+    PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * std::max(grid, 4096)));
+    PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    if (all_opt) PARTLS_HIP_CHECK(c->allOpt.ensure((size_t)npat * sizeof(double)));
+    if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
+
+    SweepParams p{};
+    p.n = n; p.kbits = c->kbits;
+    p.mask = c->maskd.as<uint64_t>();
+    p.T0 = c->use_reg ? c->T0reg.as<double>() : c->Tfull.as<double>();
+    p.scratch = c->scratch.as<double>();
+    p.g_begin = g_begin; p.g_end = g_end; p.chain_len = chain_len;
+    p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
+    p.all_opt = all_opt ? c->allOpt.as<double>() : nullptr;
+    p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
+    p.n_unconverged = c->counters.as<unsigned long long>();
+    p.n_pivots = c->counters.as<unsigned long long>() + 1;
+    p.sol = nullptr; p.sol_obj2 = nullptr; p.free_var = nullptr;
+
+    t_begin(c, PARTLS_T_SWEEP);
+    if (c->use_reg) PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, grid, c->stream));
+    else PARTLS_HIP_CHECK(launch_sweep_generic(p, grid, c->stream));
+    t_end(c, PARTLS_T_SWEEP);
+
+    std::vector<double> bo((size_t)grid);
+    std::vector<int64_t> bp((size_t)grid);
+    unsigned long long cnt[2] = {0, 0};
+    PARTLS_HIP_CHECK(hipMemcpyAsync(bo.data(), c->bestObj.p, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(bp.data(), c->bestPat.p, (size_t)grid * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    if (all_opt) {
+        // only the entries of this shard are defined; the caller merges shards (entries are indexed by pattern)
+        PARTLS_HIP_CHECK(hipMemcpyAsync(all_opt, c->allOpt.p, (size_t)npat * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    t_collect(c);
+    c->last_pivots = cnt[1];
+    double bobj = INFINITY;
+    int64_t bpat = -1;
+    for (int i = 0; i < grid; ++i) {                     // argmin with first-index tie-break (Opt.jl:96)
+        if (bp[(size_t)i] < 0) continue;
+        if (bpat < 0 || bo[(size_t)i] < bobj || (bo[(size_t)i] == bobj && bp[(size_t)i] < bpat)) { bobj = bo[(size_t)i]; bpat = bp[(size_t)i]; }
+    }
+    if (best_obj) *best_obj = bobj;
+    if (best_pattern) *best_pattern = bpat;
+    if (n_unconverged) *n_unconverged = (int64_t)cnt[0];
+    return PARTLS_OK;
+}
+
+partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, double *beta, double *t, double *opt,
+                                int64_t *best_index)
+{
+    if (!c || !c->prepared) { set_error("partls_opt_finish: context not prepared"); return PARTLS_ERR_STATE; }
+    if (!alpha || !beta || !t || !opt) { set_error("partls_opt_finish: NULL output"); return PARTLS_ERR_BAD_ARG; }
+    if (pattern < 0 || pattern >= ((int64_t)1 << (c->K + 1))) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    const uint64_t kmask = ((uint64_t)1 << c->kbits) - 1;
+    std::vector<double> sol, w;
+    unsigned long long unconv = 0;
+    t_begin(c, PARTLS_T_FINISH);
+    partls_status st = solve_single(c, (uint64_t)pattern & kmask, nullptr, nullptr, sol, nullptr, &unconv);
+    if (st != PARTLS_OK) return st;
+    unscale_solution(c, sol, w);
+    uint64_t full = (uint64_t)pattern & kmask;
+    if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
+    else full = (uint64_t)pattern;
+    st = data_objective(c, w, opt);
+    t_end(c, PARTLS_T_FINISH);
+    if (st != PARTLS_OK) return st;
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    t_collect(c);
+    cleanup_opt(c, w, full, alpha, beta, t);
+    if (best_index) *best_index = (int64_t)full;
+    if (unconv) { set_error("winner re-solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+
+partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alpha, double *optval)
+{
+    if (!c || !c->prepared) { set_error("partls_opt_pattern: context not prepared"); return PARTLS_ERR_STATE; }
+    if (!c->faithful) { set_error("partls_opt_pattern needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (pattern < 0 || pattern >= ((int64_t)1 << c->kbits)) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> sol, w;
+    unsigned long long unconv = 0;
+    partls_status st = solve_single(c, (uint64_t)pattern, nullptr, nullptr, sol, nullptr, &unconv);
+    if (st != PARTLS_OK) return st;
+    unscale_solution(c, sol, w);
+    if (optval) { st = data_objective(c, w, optval); if (st != PARTLS_OK) return st; }
+    if (raw_alpha)
+        for (int64_t m = 0; m <= c->M; ++m) {
+            const int f = 2 * __builtin_popcountll(c->mask_aug[(size_t)m] & (uint64_t)pattern) - __builtin_popcountll(c->mask_aug[(size_t)m]);
+            const double a = (f != 0) ? w[(size_t)m] / (double)f : 0.0;
+            raw_alpha[m] = a > 0.0 ? a : 0.0;
+        }
+    if (unconv) { set_error("pattern solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+
+partls_status partls_fit_opt(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                             const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
+                             double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt)
+{
+    if (all_opt) flags |= PARTLS_OPT_FAITHFUL_INTERCEPT;
+    partls_status st = partls_opt_prepare(c, X, N, M, ldX, y, 0, P, K, ldP, eta, flags);
+    if (st != PARTLS_OK) return st;
+    double bobj; int64_t bpat, unconv;
+    st = partls_opt_sweep(c, 0, -1, &bobj, &bpat, all_opt, &unconv);
+    if (st != PARTLS_OK) return st;
+    if (bpat < 0) { set_error("sweep produced no candidate"); return PARTLS_ERR_NOT_CONVERGED; }
+    st = partls_opt_finish(c, bpat, alpha, beta, t, opt, best_index);
+    if (st != PARTLS_OK) return st;
+    if (unconv) { set_error("%lld subproblems hit the pivot cap", (long long)unconv); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+
+partls_status partls_predict(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const int64_t *P, int64_t K,
+                             int64_t ldP, const double *alpha, const double *beta, double t, double *yhat)
+{
+    partls_status st = check_common(c, X, N, M, ldX, P, K, ldP);
+    if (st != PARTLS_OK) return st;
+    if (!alpha || !beta || !yhat) { set_error("partls_predict: NULL argument"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    std::vector<double> w((size_t)M, 0.0);
+    for (int64_t m = 0; m < M; ++m) {
+        double s = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+            const int64_t v = P[m + k * ldP];
+            if (v != 0 && v != 1) { set_error("P has an entry outside {0,1}"); return PARTLS_ERR_BAD_PARTITION; }
+            s += (double)v * alpha[m] * beta[k];
+        }
+        w[(size_t)m] = s;
+    }
+    DevBuf dX, dyh, dw;
+    partls_status rc = PARTLS_OK;
+    do {
+        if (dX.ensure((size_t)N * M * sizeof(double)) != hipSuccess || dyh.ensure((size_t)N * sizeof(double)) != hipSuccess ||
+            dw.ensure((size_t)M * sizeof(double)) != hipSuccess) { set_error("hipMalloc failed in partls_predict"); rc = PARTLS_ERR_HIP; break; }
+        if (hipMemcpy2DAsync(dX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double), (size_t)N * sizeof(double),
+                             (size_t)M, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(dw.p, w.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("H2D copy failed"); rc = PARTLS_ERR_HIP; break; }
+        if (launch_residual(dX.as<double>(), N, M, N, nullptr, dw.as<double>(), t, nullptr, 1024, dyh.as<double>(), c->stream) != hipSuccess) { set_error("predict kernel launch failed"); rc = PARTLS_ERR_HIP; break; }
+        if (hipMemcpyAsync(yhat, dyh.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { set_error("D2H copy failed"); rc = PARTLS_ERR_HIP; break; }
+    } while (0);
+    dX.release(); dyh.release(); dw.release();
+    return rc;
+}
+
+partls_status partls_synth_truth(uint64_t seed, int64_t D, int64_t K, int64_t *P, double *wstar)
+{
+    if (D < 1 || K < 1 || K > D) { set_error("partls_synth_truth: bad D/K"); return PARTLS_ERR_BAD_ARG; }
+    std::vector<int64_t> grp((size_t)D);
+    int64_t j = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t sz = D / K + ((k < D % K) ? 1 : 0);
+        for (int64_t q = 0; q < sz; ++q) grp[(size_t)j++] = k;
+    }
+    if (P) {
+        memset(P, 0, (size_t)D * K * sizeof(int64_t));
+        for (int64_t m = 0; m < D; ++m) P[m + grp[(size_t)m] * D] = 1;
+    }
+    auto uni = [&](uint64_t stream, uint64_t idx) { return (double)(rnd64(seed, stream, idx) >> 11) * 0x1.0p-53; };
+    if (wstar)
+        for (int64_t k = 0; k < K; ++k) {
+            double sum = 0.0;
+            for (int64_t m = 0; m < D; ++m) if (grp[(size_t)m] == k) sum += uni(2, (uint64_t)m);
+            const double bk = (uni(3, (uint64_t)k) - 0.5) * 10.0;
+            for (int64_t m = 0; m < D; ++m) if (grp[(size_t)m] == k) wstar[m] = (uni(2, (uint64_t)m) / sum) * bk;
+        }
+    return PARTLS_OK;
+}
+
+partls_status partls_synth_device(partls_ctx *c, uint64_t seed, int64_t N, int64_t D, const double *wstar, double *dX, double *dy)
+{
+    if (!c || !wstar || !dX || !dy || N < 1 || D < 1) { set_error("partls_synth_device: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    PARTLS_HIP_CHECK(c->wdev.ensure((size_t)D * sizeof(double)));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, wstar, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(launch_synth(seed, N, D, c->wdev.as<double>(), dX, dy, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return PARTLS_OK;
+}
+
+partls_status partls_get_timing(const partls_ctx *c, partls_timer which, double *ms)
+{
+    if (!c || !ms || (int)which < 0 || (int)which >= PARTLS_T_COUNT) { set_error("partls_get_timing: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *ms = c->ms[(int)which];
+    return PARTLS_OK;
+}
+
+partls_status partls_get_gram(const partls_ctx *c, double *G_aug)
+{
+    if (!c || !c->prepared || !G_aug) { set_error("partls_get_gram: context not prepared"); return PARTLS_ERR_STATE; }
+    const int na = (int)c->M + 2;
+    for (int j = 0; j < na; ++j)
+        for (int i = 0; i < na; ++i) G_aug[(size_t)i + (size_t)j * na] = h_reg(c, i, j);
+    return PARTLS_OK;
+}
+
+}  // extern "C"

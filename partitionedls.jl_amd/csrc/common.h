@@ -1,0 +1,77 @@
+// common.h — internal declarations shared by the HIP translation units of libpartls_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include <string>
+#include "../../include/partls.h"
+
+namespace partls {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// error plumbing: no exception crosses the C ABI; every entry point returns a status and records a message.
+// ---------------------------------------------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+#define PARTLS_HIP_CHECK(expr)                                                                      \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            ::partls::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PARTLS_ERR_HIP;                                                                  \
+        }                                                                                           \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sweep parameters (shared by the register-resident and the global-memory tableau kernels)
+// ---------------------------------------------------------------------------------------------------------------------
+struct SweepParams {
+    int n;                       // tableau variables (features [+ intercept when it is sign-constrained])
+    int kbits;                   // bits of the pattern space (K' = number of groups that carry a sign)
+    const uint64_t *mask;        // [n] group-membership bit mask of every variable (bit k = member of group k)
+    const double *T0;            // initial tableau, kernel-specific layout
+    double *scratch;             // generic kernel: per-workgroup tableau scratch
+    int64_t g_begin, g_end;      // Gray-index range [g_begin, g_end)
+    int64_t chain_len;           // patterns per chain (fresh tableau at the start of every chain)
+    double tol;                  // feasibility tolerance on the rhs column (scaled units)
+    double piv_eps;              // an entering pivot below this is treated as a dependent column and skipped
+    int max_rounds;              // cap on exchange rounds per pattern
+    double *all_opt;             // optional [2^kbits] objective per pattern index
+    double *best_obj;            // [gridDim.x] per-workgroup minimum objective
+    int64_t *best_pat;           // [gridDim.x] its pattern index (lexicographic tie-break on the index)
+    unsigned long long *n_unconverged;   // patterns that hit max_rounds
+    unsigned long long *n_pivots;        // total pivots (diagnostics / flop accounting)
+    // single-pattern dump (finish / opt_pattern / Alt / BnB): when sol != nullptr the LAST pattern's rhs column and
+    // basis flags are written out: sol[n] = scaled solution (0 for nonbasic), and sol_obj2 = corner.
+    double *sol;
+    double *sol_obj2;
+    // BnB: per-variable state override; nullptr for Opt. state[i]: 0 = sign from pattern, 1 = free (always basic)
+    const uint8_t *free_var;
+};
+
+// launchers (each returns hipError_t of the launch)
+hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);
+hipError_t launch_sweep_reg(const SweepParams &p, int T, int grid, hipStream_t s);
+bool       sweep_reg_supported(int n);
+int        sweep_reg_tiles(int n);
+size_t     sweep_reg_t0_doubles(int T);                  // size of the tile-cyclic initial tableau
+hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, hipStream_t s);
+
+// gram build: G_aug = Z'Z with Z = [X 1 y]  (n_aug = M + 2), full symmetric, ld = ldg (multiple of 64)
+size_t     gram_slab_doubles(int64_t N, int64_t M, int *chunks_out, int *ldg_out);
+hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, double *slab, int chunks,
+                       int ldg, double *G, hipStream_t s);
+
+// tableau prep: B = regularised (and, free-intercept mode, intercept-eliminated) Gram; Tfull = unit-diagonal scaled
+hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, int free_intercept,
+                       double *scale, double *Tfull, int n, hipStream_t s);
+
+// residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
+hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *w, double t,
+                           double *partial, int nblocks, double *yhat, hipStream_t s);
+hipError_t launch_synth(uint64_t seed, int64_t N, int64_t D, const double *wstar_dev, double *X, double *y, hipStream_t s);
+hipError_t launch_finite_check(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int *flag, hipStream_t s);
+
+// host-side mirror of the device generator (synth.hip); also used by partls_synth_truth
+uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t idx);
+
+}  // namespace partls

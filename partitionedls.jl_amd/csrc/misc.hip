@@ -1,0 +1,194 @@
+// misc.hip — the small kernels either side of the sweep: synthetic inputs, tableau preparation, residual from the data.
+#include "common.h"
+
+namespace partls {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Synthetic inputs: integer-exact counter-based generator — the device twin of oracle_synth().
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ static inline uint64_t sm64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ static inline uint64_t rnd64_hd(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    return sm64(sm64(seed ^ (stream * 0xD6E8FEB86659FD93ULL)) + idx);
+}
+uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t idx) { return rnd64_hd(seed, stream, idx); }
+
+__device__ static inline double gauss12(uint64_t seed, uint64_t stream, uint64_t idx)
+{
+    uint64_t s = 0;
+#pragma unroll
+    for (uint64_t r = 0; r < 3; ++r) {
+        const uint64_t h = rnd64_hd(seed, stream, idx * 3 + r);
+        s += (h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48);
+    }
+    return ((double)(int64_t)s - 393210.0) * 0x1.0p-16;
+}
+
+__global__ void synth_x_kernel(uint64_t seed, int64_t total, double *__restrict__ X)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        X[i] = gauss12(seed, 1, (uint64_t)i);
+}
+
+__global__ void synth_y_kernel(uint64_t seed, int64_t N, int64_t D, const double *__restrict__ X,
+                               const double *__restrict__ wstar, double *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double acc = 0.0;
+    for (int64_t j = 0; j < D; ++j) acc = fma(X[i + j * N], wstar[j], acc);      // same order as oracle_synth
+    y[i] = fma(0.1, gauss12(seed, 4, (uint64_t)i), acc + 1.0);
+}
+
+hipError_t launch_synth(uint64_t seed, int64_t N, int64_t D, const double *wstar_dev, double *X, double *y, hipStream_t s)
+{
+    const int64_t total = N * D;
+    int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(synth_x_kernel, dim3(blocks), dim3(256), 0, s, seed, total, X);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(synth_y_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, seed, N, D, X, wstar_dev, y);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NaN/Inf screen of the inputs (PARTLS_ERR_NONFINITE)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void finite_check_kernel(const double *__restrict__ X, int64_t N, int64_t M, int64_t ldX,
+                                    const double *__restrict__ y, int *flag)
+{
+    const int64_t total = N * (M + 1);
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i / N, r = i - c * N;
+        const double v = (c < M) ? X[r + c * ldX] : y[r];
+        bad |= !isfinite(v);
+    }
+    if (bad) atomicExch(flag, 1);
+}
+
+hipError_t launch_finite_check(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int *flag, hipStream_t s)
+{
+    hipLaunchKernelGGL(finite_check_kernel, dim3(2048), dim3(256), 0, s, X, N, M, ldX, y, flag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Tableau preparation.  Input: G_aug ((M+2)^2, variables [features, intercept, y]).
+//   1. regularisation, PartitionedLS.jl:108-123 in Gram form: G[a][b] += eta * #(groups containing both a and b)
+//      (the K' extra rows sqrt(eta)*1_{group k}; y is padded with zeros so c and yy are unchanged);
+//   2. free-intercept mode: eliminate the (always passive) intercept by a Schur complement;
+//   3. scale to unit diagonal, s_i = 1/sqrt(B_ii) (sign constraints are invariant under positive scaling);
+//   4. emit the full symmetric tableau  T = [[B~, c~], [c~', yy]]  ((n+1)^2, ld = n+1).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ static inline double reg_entry(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, int a, int b)
+{
+    double v = G[(size_t)a * ldg + b];
+    if (eta != 0.0 && a <= M && b <= M) v += eta * (double)__popcll(mask_aug[a] & mask_aug[b]);
+    return v;
+}
+
+__device__ static inline double base_entry(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug,
+                                           int free_intercept, int n, int i, int j)
+{
+    // tableau index -> augmented Gram index: variables 0..n-1 then the rhs (y) at index n
+    const int a = (i < n) ? i : M + 1, b = (j < n) ? j : M + 1;
+    double v = reg_entry(G, ldg, M, eta, mask_aug, a, b);
+    if (free_intercept) {
+        const double gII = reg_entry(G, ldg, M, eta, mask_aug, M, M);
+        v -= reg_entry(G, ldg, M, eta, mask_aug, a, M) * reg_entry(G, ldg, M, eta, mask_aug, M, b) / gII;
+    }
+    return v;
+}
+
+__global__ void prep_scale_kernel(const double *__restrict__ G, int ldg, int M, double eta,
+                                  const uint64_t *__restrict__ mask_aug, int free_intercept, int n, double *__restrict__ scale)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = base_entry(G, ldg, M, eta, mask_aug, free_intercept, n, i, i);
+    const double ref = G[(size_t)i * ldg + i];
+    // a (numerically) null column carries no information: scale 0 keeps it out of every basis
+    scale[i] = (d > 0.0 && d > 1e-14 * fabs(ref)) ? 1.0 / sqrt(d) : 0.0;
+}
+
+__global__ void prep_tableau_kernel(const double *__restrict__ G, int ldg, int M, double eta,
+                                    const uint64_t *__restrict__ mask_aug, int free_intercept, int n,
+                                    const double *__restrict__ scale, double *__restrict__ Tfull)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ld = n + 1;
+    if (idx >= ld * ld) return;
+    const int i = idx / ld, j = idx % ld;
+    const double si = (i < n) ? scale[i] : 1.0, sj = (j < n) ? scale[j] : 1.0;
+    double v = base_entry(G, ldg, M, eta, mask_aug, free_intercept, n, i, j) * si * sj;
+    if (i == j && i < n && si == 0.0) v = 1.0;          // dead variable: harmless unit pivot, never selected
+    Tfull[idx] = v;
+}
+
+hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, int free_intercept,
+                       double *scale, double *Tfull, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(prep_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, G, ldg, M, eta, mask_aug,
+                       free_intercept, n, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int tot = (n + 1) * (n + 1);
+    hipLaunchKernelGGL(prep_tableau_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, G, ldg, M, eta, mask_aug,
+                       free_intercept, n, scale, Tfull);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Residual from the data (Opt.jl:90 / predict PartitionedLS.jl:132-134): one coalesced pass over column-major X.
+//   partial[b] = sum over the block's rows of (sum_m X[i,m] w[m] + t - y[i])^2 ;  yhat (optional) = X w + t
+// Blocks are summed on the host in index order (reproducible).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void residual_kernel(const double *__restrict__ X, int64_t N, int64_t M, int64_t ldX,
+                                                       const double *__restrict__ y, const double *__restrict__ w, double t,
+                                                       double *__restrict__ partial, double *__restrict__ yhat)
+{
+    extern __shared__ double sw[];                       // w staged once per block
+    for (int64_t m = threadIdx.x; m < M; m += blockDim.x) sw[m] = w[m];
+    __syncthreads();
+    double acc2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int64_t m = 0;
+        for (; m + 3 < M; m += 4) {
+            a0 = fma(X[i + m * ldX], sw[m], a0);
+            a1 = fma(X[i + (m + 1) * ldX], sw[m + 1], a1);
+            a2 = fma(X[i + (m + 2) * ldX], sw[m + 2], a2);
+            a3 = fma(X[i + (m + 3) * ldX], sw[m + 3], a3);
+        }
+        for (; m < M; ++m) a0 = fma(X[i + m * ldX], sw[m], a0);
+        const double p = ((a0 + a1) + (a2 + a3)) + t;
+        if (yhat) yhat[i] = p;
+        if (y) { const double r = p - y[i]; acc2 = fma(r, r, acc2); }
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = acc2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = red[0];
+}
+
+hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *w, double t,
+                           double *partial, int nblocks, double *yhat, hipStream_t s)
+{
+    hipLaunchKernelGGL(residual_kernel, dim3(nblocks), dim3(256), (size_t)M * sizeof(double), s, X, N, M, ldX, y, w, t,
+                       partial, yhat);
+    return hipGetLastError();
+}
+
+}  // namespace partls

@@ -1,0 +1,163 @@
+// sweep_generic.hip — sign-pattern sweep with the tableau in global memory (one workgroup per Gray-code chain).
+//
+// Replaces the loop body of fit(Opt) — indextobeta + bmatrix + nonneg_lsq + objective, Opt.jl:87-90 — for a whole
+// range of patterns, and the node bound of BnB (BnB.jl:69-92) / the α-step of Alt (Alt.jl:80-90) for single patterns.
+//
+// Algorithm.  The subproblem of pattern s is  min ||Xo w - y||  s.t.  f_m w_m >= 0  with
+// f_m = sum_k Po[m,k] s_k (Opt.jl:28-29); it depends on the data only through the Gram block.  We keep the symmetric
+// principal-pivot tableau of the current passive ("basic") set B:
+//        T = sweep_B [[G, c], [c', yy]]   =>   T[i][n] = w_i (i in B),  T[i][n] = c_i - G_iB w_B (i not in B),  T[n][n] = obj^2
+// which does NOT depend on the signs.  KKT for pattern s reads off the rhs column:  f_i w_i >= 0 (i in B),
+// f_i (c - G w)_i <= 0 (i not in B).  Consecutive patterns of a Gray-code walk differ in one group, so only that
+// group's variables (plus a few neighbours) violate KKT: they are exchanged by block principal pivoting
+// (all violators at once; Kim & Park's finite-termination backup rule), one symmetric rank-1 sweep per variable:
+//        T_ij -= T_ik T_kj / d ,  T_ik = T_ik / |d| ,  T_kk = -1/d        (d = T_kk; the same formula enters and removes).
+// This kernel is the fully general, simple form: full (n+1)^2 tableau per workgroup in global scratch (L2 resident).
+// The register-resident production kernel is sweep_reg.hip; both share SweepParams and must agree bit-for-bit in
+// their decisions up to rounding.
+#include "common.h"
+
+namespace partls {
+
+static constexpr int GEN_THREADS = 256;
+static constexpr int GEN_MAXWORDS = 16;     // n <= 1024
+
+__device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat)
+{
+    // f = sum_k P[v,k] * s_k with s_k = +1 if bit k of pat else -1  ==  2*popc(m & pat) - popc(m)
+    return 2 * __popcll(m & pat) - __popcll(m);
+}
+
+__global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams p)
+{
+    const int n = p.n, ld = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ double smem[];
+    double *r = smem;                                             // pivot column, ld doubles
+    uint8_t *s_basic = reinterpret_cast<uint8_t *>(smem + ld);    // n bytes
+    uint8_t *s_blocked = s_basic + n;                             // n bytes
+    __shared__ unsigned long long s_inf[GEN_MAXWORDS];
+    __shared__ int s_skip;
+
+    double *T = p.scratch + (size_t)blockIdx.x * (size_t)ld * (size_t)ld;
+    const int nwords = (n + 63) >> 6;
+
+    double best_obj = __builtin_inf();
+    long long best_pat = -1;
+    unsigned long long npiv = 0, nunconv = 0;
+
+    const int64_t total = p.g_end - p.g_begin;
+    const int64_t nchains = (total + p.chain_len - 1) / p.chain_len;
+
+    // one symmetric principal pivot on variable k (uniform call)
+    auto pivot = [&](int k) -> bool {
+        for (int i = tid; i < ld; i += GEN_THREADS) r[i] = T[(size_t)k * ld + i];
+        __syncthreads();
+        const double d = r[k];
+        if (!s_basic[k] && !(d > p.piv_eps)) {                    // dependent column: Lawson–Hanson's rejection
+            __syncthreads();
+            if (tid == 0) s_blocked[k] = 1;
+            __syncthreads();
+            return false;
+        }
+        const double inv = 1.0 / d, ainv = 1.0 / fabs(d);
+        for (int i = wave; i < ld; i += GEN_THREADS / 64) {
+            const double ri = r[i], mi = -ri * inv;
+            double *row = T + (size_t)i * ld;
+            if (i == k) {
+                for (int j = lane; j < ld; j += 64) row[j] = (j == k) ? -inv : r[j] * ainv;
+            } else {
+                for (int j = lane; j < ld; j += 64) row[j] = (j == k) ? ri * ainv : fma(mi, r[j], row[j]);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_basic[k] ^= 1;
+        __syncthreads();
+        return true;
+    };
+
+    for (int64_t chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+        const int64_t g0 = p.g_begin + chain * p.chain_len;
+        const int64_t g1 = (g0 + p.chain_len < p.g_end) ? g0 + p.chain_len : p.g_end;
+        for (int idx = tid; idx < ld * ld; idx += GEN_THREADS) T[idx] = p.T0[idx];
+        for (int i = tid; i < n; i += GEN_THREADS) { s_basic[i] = 0; s_blocked[i] = 0; }
+        __syncthreads();
+        if (p.free_var)
+            for (int k = 0; k < n; ++k)
+                if (p.free_var[k]) { if (pivot(k)) ++npiv; }
+
+        for (int64_t g = g0; g < g1; ++g) {
+            const uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            for (int i = tid; i < n; i += GEN_THREADS) s_blocked[i] = 0;
+            __syncthreads();
+            int ninf_best = n + 1, patience = 3, rounds = 0;
+            for (;;) {
+                // ---- KKT scan of the rhs column -----------------------------------------------------------------
+                for (int base = 0; base < nwords * 64; base += GEN_THREADS) {
+                    const int v = base + tid;
+                    bool bad = false;
+                    if (v < n && !(p.free_var && p.free_var[v])) {
+                        const double q = T[(size_t)n * ld + v];
+                        const int f = sign_of_var(p.mask[v], pat);
+                        const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
+                        if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
+                        else bad = (fq > p.tol) && !s_blocked[v];
+                    }
+                    const unsigned long long b = __ballot(bad);
+                    if (lane == 0 && (v >> 6) < nwords) s_inf[v >> 6] = b;
+                }
+                __syncthreads();
+                int count = 0;
+                for (int w = 0; w < nwords; ++w) count += __popcll(s_inf[w]);
+                if (count == 0) break;
+                bool all;
+                if (count < ninf_best) { ninf_best = count; patience = 3; all = true; }
+                else if (patience > 0) { --patience; all = true; }
+                else all = false;                                  // backup rule: single pivot, largest index
+                if (++rounds > p.max_rounds) { ++nunconv; break; }
+                if (all) {
+                    for (int w = 0; w < nwords; ++w) {
+                        unsigned long long bits = s_inf[w];
+                        while (bits) {
+                            const int k = (w << 6) + __builtin_ctzll(bits);
+                            bits &= bits - 1;
+                            if (pivot(k)) ++npiv;
+                        }
+                    }
+                } else {
+                    int k = -1;
+                    for (int w = nwords - 1; w >= 0 && k < 0; --w)
+                        if (s_inf[w]) k = (w << 6) + 63 - __builtin_clzll(s_inf[w]);
+                    if (pivot(k)) ++npiv;
+                }
+                __syncthreads();
+            }
+            const double obj2 = T[(size_t)n * ld + n];
+            const double obj = sqrt(obj2 > 0.0 ? obj2 : 0.0);
+            if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
+            if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
+            __syncthreads();
+        }
+        if (p.sol) {                                               // single-pattern use: dump the last solution
+            for (int i = tid; i < n; i += GEN_THREADS) p.sol[i] = s_basic[i] ? T[(size_t)n * ld + i] : 0.0;
+            if (tid == 0) *p.sol_obj2 = T[(size_t)n * ld + n];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.best_obj[blockIdx.x] = best_obj;
+        p.best_pat[blockIdx.x] = best_pat;
+        if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
+        if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
+    }
+    (void)s_skip;
+}
+
+hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s)
+{
+    const size_t shmem = (size_t)(p.n + 1) * sizeof(double) + 2 * (size_t)p.n + 16;
+    hipLaunchKernelGGL(sweep_generic_kernel, dim3(grid), dim3(GEN_THREADS), shmem, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace partls
