@@ -54,6 +54,31 @@ def build(force=False):
     return SO_PATH
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, file name
+    without the version), so a process that loads /opt/rocm's copy first and torch's second ends up with two HSA runtimes
+    and torch then reports "No HIP GPUs".  When torch is installed, load ITS copy first (without importing torch): our
+    DT_NEEDED libamdhip64.so.7 then binds to it by SONAME and a later `import torch` re-uses the same file."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                   # torch already brought its runtime in; SONAME matching does the rest
+    if os.environ.get("PARTLS_NO_TORCH_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load the HIP library. Fails loudly when it is missing: there is no fallback implementation."""
     global _lib
@@ -61,6 +86,7 @@ def lib():
         if not os.path.exists(SO_PATH):
             raise ImportError(f"{SO_PATH} is missing: build it with __graft_entry__.build() "
                               f"(make -C '{CSRC}'); partitionedls.jl_amd has no CPU fallback")
+        _preload_torch_hip_runtime()
         l = C.CDLL(SO_PATH)
         for name, res, args in SYMBOLS:
             f = getattr(l, name)           # AttributeError here = header/library mismatch
