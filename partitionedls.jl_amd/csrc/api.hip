@@ -202,7 +202,12 @@ static partls_status solve_single(partls_ctx *c, uint64_t pattern, const uint64_
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
     p.sol = c->sol.as<double>(); p.sol_obj2 = c->sol.as<double>() + n;
     p.free_var = free_dev;
-    PARTLS_HIP_CHECK(launch_sweep_generic(p, 1, c->stream));
+    if (c->use_reg && !free_dev) {                      // register-resident kernel: ~n/2 pivots from the fresh tableau
+        p.T0 = c->T0reg.as<double>();
+        PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, 1, c->stream));
+    } else {
+        PARTLS_HIP_CHECK(launch_sweep_generic(p, 1, c->stream));
+    }
     sol.resize((size_t)n + 1);
     unsigned long long cnt[2] = {0, 0};
     PARTLS_HIP_CHECK(hipMemcpyAsync(sol.data(), c->sol.p, (size_t)(n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));

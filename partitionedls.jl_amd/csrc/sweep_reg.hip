@@ -238,6 +238,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
             if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
             if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
         }
+        if (p.sol) {                                               // single-pattern use: dump the last solution
+            if (has_var) p.sol[tid] = basic ? q : 0.0;
+            if (tid == 0) *p.sol_obj2 = corner;
+        }
     }
     if (tid == 0) {
         p.best_obj[blockIdx.x] = best_obj;
