@@ -74,23 +74,14 @@ def main():
     torch.cuda.synchronize()
     flags = L.OPT_FAITHFUL_INTERCEPT if args.faithful else 0
 
-    red = torch.zeros(1, dtype=torch.float64, device=dev)
-    redi = torch.zeros(1, dtype=torch.int64, device=dev)
-
     def step():
         ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, flags)
         npat = ctx.num_patterns()
-        g0, g1 = rank * npat // world, (rank + 1) * npat // world
+        g0, g1 = pls.dist.shard_range(npat, rank, world)
         bobj, bpat, _, unconv = ctx.opt_sweep(g0, g1)
         t_gram, t_prep, t_sweep = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP)
-        if world > 1:
-            # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
-            red[0] = bobj
-            dist.all_reduce(red, op=dist.ReduceOp.MIN)
-            gmin = float(red[0])
-            redi[0] = bpat if bobj == gmin else (1 << 62)
-            dist.all_reduce(redi, op=dist.ReduceOp.MIN)
-            bpat = int(redi[0])
+        # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
+        _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=dev)
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         return dict(npat=npat, local=g1 - g0, opt=opt, best_index=bi, unconv=unconv, t_gram=t_gram, t_prep=t_prep,
                     t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), alpha=a, beta=b, t=t)

@@ -12,6 +12,7 @@ there is no CPU fallback — importing works anywhere, computing needs an MI355X
 from .api import (Alt, BnB, Context, Opt, PartLSFitResult, PartlsError, Report, build_library, default_context, fit,
                   homogeneousCoords, library_path, predict, regularizeProblem, synth_truth)
 from . import _lib as lowlevel
+from . import dist
 
 __all__ = ["fit", "predict", "PartLSFitResult", "Opt", "Alt", "BnB", "homogeneousCoords", "regularizeProblem",
-           "PartlsError", "Report", "build_library", "library_path", "lowlevel", "Context", "default_context", "synth_truth"]
+           "PartlsError", "Report", "build_library", "library_path", "lowlevel", "Context", "default_context", "synth_truth", "dist"]
