@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libpartls_hip.so")
+SO_PATH = os.environ.get("PARTLS_LIB") or os.path.join(_HERE, "libpartls_hip.so")   # PARTLS_LIB: diagnostic builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 OK, ERR_BAD_ARG, ERR_BAD_PARTITION, ERR_NONFINITE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED, ERR_STATE = range(9)

@@ -204,7 +204,9 @@ static partls_status solve_single(partls_ctx *c, uint64_t pattern, const uint64_
     p.free_var = free_dev;
     if (c->use_reg && !free_dev) {                      // register-resident kernel: ~n/2 pivots from the fresh tableau
         p.T0 = c->T0reg.as<double>();
-        PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, 1, c->stream));
+        const char *kv = getenv("PARTLS_KERNEL");
+        if (kv && strcmp(kv, "reg") == 0) PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, 1, c->stream));
+        else PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, 1, c->stream));
     } else {
         PARTLS_HIP_CHECK(launch_sweep_generic(p, 1, c->stream));
     }
@@ -394,6 +396,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
     if (all_opt) PARTLS_HIP_CHECK(c->allOpt.ensure((size_t)npat * sizeof(double)));
     if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
+    else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
 
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
@@ -409,8 +412,11 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.sol = nullptr; p.sol_obj2 = nullptr; p.free_var = nullptr;
 
     t_begin(c, PARTLS_T_SWEEP);
-    if (c->use_reg) PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, grid, c->stream));
-    else PARTLS_HIP_CHECK(launch_sweep_generic(p, grid, c->stream));
+    if (c->use_reg) {
+        const char *kv = getenv("PARTLS_KERNEL");          // "reg" = rank-1 register kernel (A/B), default = blocked pivots
+        if (kv && strcmp(kv, "reg") == 0) PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, grid, c->stream));
+        else PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, grid, c->stream));
+    } else PARTLS_HIP_CHECK(launch_sweep_generic(p, grid, c->stream));
     t_end(c, PARTLS_T_SWEEP);
 
     std::vector<double> bo((size_t)grid);
@@ -426,6 +432,12 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
     c->last_pivots = cnt[1];
+    if (getenv("PARTLS_PRINT_STAMPS")) {                 // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
+        double st[8];
+        if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[partls stamps] scan %.0f gather %.0f panel %.0f update %.0f scatter %.0f chain-load %.0f/%.0f pivots %llu\n",
+                    st[0], st[1], st[2], st[3], st[4], st[5], st[6], cnt[1]);
+    }
     double bobj = INFINITY;
     int64_t bpat = -1;
     for (int i = 0; i < grid; ++i) {                     // argmin with first-index tie-break (Opt.jl:96)

@@ -1,0 +1,381 @@
+// sweep_blk.hip — production sign-pattern sweep, BLOCKED principal pivots on a register-resident tableau.
+//
+// Replaces the loop body of fit(Opt), Opt.jl:87-90, for every pattern of a Gray-code chain (same mathematics and the
+// same per-pattern decisions as sweep_generic.hip / sweep_reg.hip).  What is new relative to sweep_reg.hip:
+// the violators of one KKT scan are exchanged one 16x16 TILE COLUMN at a time as a block pivot
+//     T'_RR = T_RR - sum_s z_s z_s' / d_s          (z_s = pivot column as of its own step, d_s its pivot)
+// so that the expensive part — the update of the register tableau — is ONE fused rank-m pass of uninterrupted FMAs, and
+// the per-pivot overheads of the rank-1 kernel (column gather under a scalar if-chain, barrier, LDS round trip, fix-up
+// if-chain) are paid once per tile instead of once per pivot:
+//   1. gather   : every thread writes its slots of tile column kappa to an LDS panel P[16 cols][rows] (+ rhs row);
+//   2. panel    : thread t owns ROW t of the panel in registers (<= 16 pivot columns); m sequential Gauss–Jordan steps,
+//                 each exchanging only the m pivot-row entries through LDS (one barrier per step); z_s and 1/d_s recorded;
+//   3. update   : all 512 threads: S(rho,gamma) -= x_s[rho] * y_s[gamma] for s = 1..m (x resident, y streamed from LDS);
+//   4. scatter  : rows/columns of the pivoted variables are overwritten from the final panel (one if-chain per tile).
+// Layout of the register tableau, thread grid, half split and LDS image are those of sweep_reg.hip.
+#include "common.h"
+
+namespace partls {
+namespace blk {
+
+static constexpr int THREADS = 512;
+static constexpr int MAXT = 17;                 // n <= 272
+static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks)
+
+constexpr int nslots(int T) { return T * (T + 1) / 2; }
+constexpr int tri(int g) { return g * (g + 1) / 2; }
+constexpr int split(int T)
+{
+    int best = 1, bestmax = 1 << 30;
+    for (int g = 1; g < T; ++g) {
+        int a = tri(g), b = nslots(T) - tri(g);
+        int m = a > b ? a : b;
+        if (m < bestmax) { bestmax = m; best = g; }
+    }
+    return T == 1 ? 1 : best;
+}
+constexpr int rstride(int T) { return (T % 2) ? T : T + 1; }      // odd row stride: 16 lanes x 8 B hit 32 distinct banks
+constexpr int colw(int T) { return 16 * rstride(T) + 1; }          // panel column: 16*RS row positions + rhs row (odd)
+// LDS doubles: P[2][MB][COLW], Z[MB][COLW], U[2][MB], Dinv[MB]; then 32 x u64 masks
+constexpr int lds_doubles(int T) { return 3 * MB * colw(T) + 2 * MB + MB; }
+
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return y;
+}
+__device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
+
+// Diagnostic build only (-DPARTLS_STAMPS): per-phase cycle shares of workgroup 0 / thread 0, written to p.scratch[0..7]
+// (a buffer no other code of the kernel reads).  Never quote this build's run time (cdna_hip_programming.md §7).
+#ifdef PARTLS_STAMPS
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+                       st_acc[ph] += _n - st_t; st_t = _n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_FLUSH do { if (tid == 0 && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 8; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(ph) do { } while (0)
+#define STAMP_FLUSH do { } while (0)
+#endif
+
+template <int T, int H>
+struct Half {
+    static constexpr int G = split(T);
+    static constexpr int GLO = H ? G : 0;
+    static constexpr int GHI = H ? T : G;
+    static constexpr int OFF = H ? tri(G) : 0;
+    static constexpr int CNT = (H ? nslots(T) - tri(G) : tri(G)) > 0 ? (H ? nslots(T) - tri(G) : tri(G)) : 1;
+    static constexpr int XN = GHI;
+    static constexpr int RS = rstride(T);
+    static constexpr int CW = colw(T);
+    __device__ static constexpr int idx(int rho, int gam) { return tri(gam) + rho - OFF; }
+};
+
+// ---- tile-column gather ------------------------------------------------------------------------------------------------
+// Element (16 rho + a, 16 KAPPA + b) belongs to column b of the tile, row position a*RS + rho.  Only the pivot columns are
+// gathered, COMPACTED: the j-th pivot of the block (ascending local index) becomes panel column j = popc(pm below it).
+template <int T, int H, int KAPPA, class SA>
+__device__ __forceinline__ void gather_tile(const SA &S, double *P, int a, int b, unsigned pm)
+{
+    using L = Half<T, H>;
+    if constexpr (KAPPA >= L::GLO && KAPPA < L::GHI) {
+        if ((pm >> b) & 1u) {
+            double *col = P + __builtin_popcount(pm & ((1u << b) - 1u)) * L::CW + a * L::RS;
+#pragma unroll
+            for (int rho = 0; rho <= KAPPA; ++rho) col[rho] = S[L::idx(rho, KAPPA)];
+        }
+    }
+    // row KAPPA of the stored triangle = column (16 KAPPA + a) by symmetry, row position b*RS + gamma
+    if ((pm >> a) & 1u) {
+        double *col = P + __builtin_popcount(pm & ((1u << a) - 1u)) * L::CW + b * L::RS;
+#pragma unroll
+        for (int gam = (KAPPA + 1 > L::GLO ? KAPPA + 1 : L::GLO); gam < L::GHI; ++gam) col[gam] = S[L::idx(KAPPA, gam)];
+    }
+}
+
+template <int T, int H, int KAPPA, class SA>
+__device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int b, unsigned pm)
+{
+    using L = Half<T, H>;
+    if constexpr (KAPPA >= L::GLO && KAPPA < L::GHI) {
+        if ((pm >> b) & 1u) {
+            const double *col = P + __builtin_popcount(pm & ((1u << b) - 1u)) * L::CW + a * L::RS;
+#pragma unroll
+            for (int rho = 0; rho <= KAPPA; ++rho) S[L::idx(rho, KAPPA)] = col[rho];
+        }
+    }
+    if ((pm >> a) & 1u) {
+        const double *col = P + __builtin_popcount(pm & ((1u << a) - 1u)) * L::CW + b * L::RS;
+#pragma unroll
+        for (int gam = (KAPPA > L::GLO ? KAPPA : L::GLO); gam < L::GHI; ++gam) S[L::idx(KAPPA, gam)] = col[gam];
+    }
+}
+
+// ---- panel elimination for a block of m <= M pivots (M in {1,2,4,8}); straight-line inside a step ------------------------
+// Thread t owns row position t of the m (compacted) pivot columns in registers pv[0..M).  Step s: the pivot-row threads
+// publish their entry of column s through U, the thread that is pivot row s also publishes 1/d (or 0 for a dependent
+// column, Lawson–Hanson's rejection), one barrier, one batch of broadcast reads, then every thread updates its own row.
+template <int M, int RS, int CW>
+__device__ __forceinline__ void panel_block(double *P, double *Z, double *U, double *Dinv, int m, int myj, bool my_basic,
+                                            double piv_eps, int tid)
+{
+    constexpr int RHSPOS = 16 * RS;
+    const bool rowok = tid <= RHSPOS;
+    double pv[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) pv[j] = P[(j < m ? j : 0) * CW + tid];        // j >= m: dummy copy of column 0, never stored
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        if (s < m) {
+            if (rowok) Z[s * CW + tid] = pv[s];
+            if (myj >= 0) U[(s & 1) * MB + myj] = pv[s];
+            if (myj == s) {
+                const double d = pv[s];
+                Dinv[s] = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
+            }
+            __syncthreads();
+            const double inv = Dinv[s], ainv = fabs(inv);
+            double u[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * MB + j];
+            const bool ok = inv != 0.0, isrow = (myj == s);
+            const double fz = pv[s] * inv;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (j == s) continue;
+                const double upd = isrow ? u[j] * ainv : fma(-fz, u[j], pv[j]);
+                pv[j] = ok ? upd : pv[j];
+            }
+            pv[s] = ok ? (isrow ? -inv : pv[s] * ainv) : pv[s];
+        }
+    }
+    if (rowok) {
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            if (j < m) P[j * CW + tid] = pv[j];
+    }
+}
+
+#define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
+
+template <int T, int H>
+__device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
+{
+    using L = Half<T, H>;
+    constexpr int RS = L::RS, CW = L::CW, RHSPOS = 16 * RS;
+    const int tid = threadIdx.x, t8 = tid & 255, a = t8 & 15, b = t8 >> 4, lane = tid & 63, wave = tid >> 6;
+    const int n = p.n;
+    const int nwords = (n + 63) >> 6;
+
+    double *Pbase = lds;                                  // [2][MB][CW]
+    double *Z = lds + 2 * MB * CW;                        // [MB][CW]
+    double *U = Z + MB * CW;                              // [2][MB]
+    double *Dinv = U + 2 * MB;                            // [MB]
+    unsigned long long *s_inf = reinterpret_cast<unsigned long long *>(Dinv + MB);   // [2][8]
+    unsigned long long *s_bas = s_inf + 16;                                            // [2][8]
+
+    for (int i = tid; i < lds_doubles(T) + 32; i += THREADS) lds[i] = 0.0;            // padding rows are never gathered
+    __syncthreads();
+
+    double S[L::CNT];
+    double q = 0.0, corner = 0.0;
+    const bool has_var = tid < n;
+    const uint64_t vmask = has_var ? p.mask[tid] : 0ULL;
+    bool basic = false, blocked = false;
+    const int mypos = (tid & 15) * RS + (tid >> 4);       // panel row position of variable `tid` (tid < 16 T)
+    // panel phase: this thread owns row position `tid`, i.e. variable 16*rowrho + rowc (valid when rowc < 16)
+    const int rowc = tid / RS, rowrho = tid - rowc * RS;
+
+    double best_obj = __builtin_inf();
+    long long best_pat = -1;
+    unsigned long long npiv = 0, nunconv = 0;
+    unsigned bc = 0, sc = 0;                              // block / scan counters (double-buffer parity)
+
+    const int64_t total = p.g_end - p.g_begin;
+    const int64_t nchains = (total + p.chain_len - 1) / p.chain_len;
+
+    STAMP_DECL
+    for (int64_t chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+        const int64_t g0 = p.g_begin + chain * p.chain_len;
+        const int64_t g1 = (g0 + p.chain_len < p.g_end) ? g0 + p.chain_len : p.g_end;
+        STAMP(5);
+#pragma unroll
+        for (int s = 0; s < L::CNT; ++s) S[s] = p.T0[(size_t)(s + L::OFF) * 256 + t8];
+        q = (tid < 16 * T) ? p.T0[(size_t)nslots(T) * 256 + tid] : 0.0;
+        corner = p.T0[(size_t)nslots(T) * 256 + 16 * T];
+        basic = false;
+        STAMP(6);
+
+        for (int64_t g = g0; g < g1; ++g) {
+            const uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            const int f = sign_of_var(vmask, pat);
+            blocked = false;
+            int ninf_best = n + 1, patience = 3, rounds = 0;
+            for (;;) {
+                // ---- KKT scan of the rhs column (registers) ------------------------------------------------------------
+                const int par = sc & 1;
+                ++sc;
+                bool bad = false;
+                if (has_var) {
+                    const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
+                    if (basic) bad = (f == 0) || (fq < -p.tol);
+                    else bad = (fq > p.tol) && !blocked;
+                }
+                const unsigned long long bb = __ballot(bad), bs = __ballot(basic);
+                if (lane == 0 && wave < nwords) { s_inf[par * 8 + wave] = bb; s_bas[par * 8 + wave] = bs; }
+                __syncthreads();
+                // mask words are read once, reduced to (count, tile mask, largest violator) and dropped
+                int count = 0, single_k = -1;
+                unsigned tiles = 0;
+#pragma unroll
+                for (int w = 0; w < 5; ++w) {
+                    const unsigned long long ww = (w < nwords) ? s_inf[par * 8 + w] : 0ULL;
+                    count += __popcll(ww);
+                    if (ww) single_k = (w << 6) + 63 - __builtin_clzll(ww);
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+                        if ((ww >> (16 * sub)) & 0xFFFFull) tiles |= 1u << (4 * w + sub);
+                }
+                STAMP(0);
+                if (count == 0) break;
+                bool all;
+                if (count < ninf_best) { ninf_best = count; patience = 3; all = true; }
+                else if (patience > 0) { --patience; all = true; }
+                else all = false;                                     // backup rule: only the largest violator
+                if (++rounds > p.max_rounds) { ++nunconv; break; }
+                if (!all) tiles = 1u << (single_k >> 4);
+                tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)tiles);
+
+                while (tiles) {
+                    const int kappa = __builtin_ctz(tiles);
+                    const int wsel = kappa >> 2, sh = 16 * (kappa & 3);
+                    unsigned pmall = (unsigned)((s_inf[par * 8 + wsel] >> sh) & 0xFFFFull);
+                    if (!all) pmall = 1u << (single_k & 15);
+                    const unsigned basm = (unsigned)__builtin_amdgcn_readfirstlane((int)((s_bas[par * 8 + wsel] >> sh) & 0xFFFFull));
+                    pmall = (unsigned)__builtin_amdgcn_readfirstlane((int)pmall);
+                    while (pmall) {
+                        // ---- block: the lowest <= MB violators of tile column kappa -------------------------------------
+                        unsigned rest = pmall;
+#pragma unroll
+                        for (int i = 0; i < MB; ++i) rest &= rest - 1;
+                        const unsigned pm = pmall & ~rest;
+                        pmall = rest;
+                        const int m = __builtin_popcount(pm);
+                        double *P = Pbase + (bc & 1) * MB * CW;
+                        ++bc;
+                        // ---- 1. gather the pivot columns (compacted) into the LDS panel ------------------------------------
+#define PARTLS_G(i) if constexpr (i < T) { if (kappa == i) gather_tile<T, H, i>(S, P, a, b, pm); }
+                        PARTLS_CASES(PARTLS_G)
+#undef PARTLS_G
+                        if (tid < 16 * T && (tid >> 4) == kappa && ((pm >> (tid & 15)) & 1u))
+                            P[__builtin_popcount(pm & ((1u << (tid & 15)) - 1u)) * CW + RHSPOS] = q;
+                        // is this thread's panel row a pivot row?  row position t <-> variable 16*rowrho + rowc
+                        int myj = -1;
+                        bool my_basic = false;
+                        if (rowrho == kappa && rowc < 16 && ((pm >> rowc) & 1u)) {
+                            myj = __builtin_popcount(pm & ((1u << rowc) - 1u));
+                            my_basic = (basm >> rowc) & 1u;
+                        }
+                        __syncthreads();
+                        STAMP(1);
+                        // ---- 2. panel elimination -----------------------------------------------------------------------
+                        if (m == 1) panel_block<1, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        else if (m == 2) panel_block<2, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        else if (m <= 4) panel_block<4, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        else panel_block<8, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        __syncthreads();
+                        STAMP(2);
+                        // ---- 3. fused rank-m update of the register tableau ------------------------------------------------
+#pragma unroll 1
+                        for (int s = 0; s < m; ++s) {
+                            const double inv = Dinv[s];
+                            const double *Zs = Z + s * CW;
+                            double x[L::XN];
+#pragma unroll
+                            for (int rho = 0; rho < L::XN; ++rho) x[rho] = Zs[a * RS + rho];
+#pragma unroll
+                            for (int gam = L::GLO; gam < L::GHI; ++gam) {
+                                const double yg = -Zs[b * RS + gam] * inv;
+#pragma unroll
+                                for (int rho = 0; rho <= gam; ++rho)
+                                    S[L::idx(rho, gam)] = fma(x[rho], yg, S[L::idx(rho, gam)]);
+                            }
+                            const double zr = Zs[RHSPOS], zri = zr * inv;
+                            if (tid < 16 * T) q = fma(-Zs[mypos], zri, q);
+                            corner = fma(-zr, zri, corner);
+                        }
+                        STAMP(3);
+                        // ---- 4. rows / columns of the pivoted variables come from the final panel ----------------------------
+#define PARTLS_F(i) if constexpr (i < T) { if (kappa == i) scatter_tile<T, H, i>(S, P, a, b, pm); }
+                        PARTLS_CASES(PARTLS_F)
+#undef PARTLS_F
+                        if (tid < 16 * T && (tid >> 4) == kappa && ((pm >> (tid & 15)) & 1u)) {
+                            const int j = __builtin_popcount(pm & ((1u << (tid & 15)) - 1u));
+                            q = P[j * CW + RHSPOS];
+                            if (Dinv[j] != 0.0) basic = !basic;
+                            else blocked = true;
+                        }
+                        npiv += (unsigned)m;
+                        STAMP(4);
+                    }
+                    tiles &= tiles - 1;
+                }
+            }
+            const double obj = sqrt(corner > 0.0 ? corner : 0.0);
+            if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
+            if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
+        }
+        if (p.sol) {
+            if (has_var) p.sol[tid] = basic ? q : 0.0;
+            if (tid == 0) *p.sol_obj2 = corner;
+        }
+    }
+    STAMP_FLUSH;
+    if (tid == 0) {
+        p.best_obj[blockIdx.x] = best_obj;
+        p.best_pat[blockIdx.x] = best_pat;
+        if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
+        if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(THREADS, 2) void sweep_blk_kernel(SweepParams p)
+{
+    extern __shared__ double lds[];
+    const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    if (half == 0) sweep_body<T, 0>(p, lds);
+    else sweep_body<T, 1>(p, lds);
+}
+
+}  // namespace blk
+
+template <int T>
+static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
+{
+    const size_t shmem = (size_t)blk::lds_doubles(T) * sizeof(double) + 32 * sizeof(unsigned long long);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blk::sweep_blk_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(blk::sweep_blk_kernel<T>, dim3(grid), dim3(blk::THREADS), shmem, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s)
+{
+    switch (T) {
+#define PARTLS_L(i) case i + 1: return launch_blk_T<i + 1>(p, grid, s);
+        PARTLS_CASES(PARTLS_L)
+#undef PARTLS_L
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace partls
