@@ -20,7 +20,10 @@ namespace blk {
 
 static constexpr int THREADS = 512;
 static constexpr int MAXT = 17;                 // n <= 272
-static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks)
+#ifndef PARTLS_MB
+#define PARTLS_MB 8
+#endif
+static constexpr int MB = PARTLS_MB;            // pivots per block (8: a tile column with more violators takes two blocks)
 
 constexpr int nslots(int T) { return T * (T + 1) / 2; }
 constexpr int tri(int g) { return g * (g + 1) / 2; }
@@ -232,7 +235,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                 unsigned tiles = 0;
 #pragma unroll
                 for (int w = 0; w < 5; ++w) {
-                    const unsigned long long ww = (w < nwords) ? s_inf[par * 8 + w] : 0ULL;
+                    unsigned long long ww = (w < nwords) ? s_inf[par * 8 + w] : 0ULL;
+                    ww = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ww >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)ww);             // uniform -> SALU bookkeeping
                     count += __popcll(ww);
                     if (ww) single_k = (w << 6) + 63 - __builtin_clzll(ww);
 #pragma unroll
@@ -285,7 +290,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         if (m == 1) panel_block<1, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
                         else if (m == 2) panel_block<2, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
                         else if (m <= 4) panel_block<4, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
-                        else panel_block<8, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        else if (m <= 8 || MB == 8) panel_block<8, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        else panel_block<MB, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
                         __syncthreads();
                         STAMP(2);
                         // ---- 3. fused rank-m update of the register tableau ------------------------------------------------
