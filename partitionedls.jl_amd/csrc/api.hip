@@ -1,12 +1,13 @@
 // api.hip — the C ABI of include/partls.h: host orchestration of the HIP kernels.  No CPU fallback: every compute
 // entry needs a HIP device and fails with PARTLS_ERR_NO_DEVICE / PARTLS_ERR_HIP otherwise.
-#include "common.h"
+#include "ctx.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <numeric>
 #include <new>
 
 namespace partls {
@@ -20,57 +21,9 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t b)
-    {
-        if (b <= bytes && p) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipMalloc(&p, b ? b : 8);
-        if (e == hipSuccess) bytes = b;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-    template <class T> T *as() const { return static_cast<T *>(p); }
-};
-
-}  // namespace partls
-
-using namespace partls;
-
-struct partls_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0[PARTLS_T_COUNT] = {}, ev1[PARTLS_T_COUNT] = {};
-    bool timed[PARTLS_T_COUNT] = {};
-    double ms[PARTLS_T_COUNT] = {};
-
-    // problem
-    bool prepared = false;
-    int64_t N = 0, M = 0, K = 0, ldX = 0;
-    double eta = 0.0;
-    uint32_t flags = 0;
-    bool faithful = false;
-    const double *dX = nullptr, *dy = nullptr;     // device views (owned copies below, or the caller's)
-    DevBuf ownX, ownY;
-    std::vector<int64_t> P;                        // M x K compact
-    std::vector<uint64_t> mask_aug;                // M + 2
-    // gram
-    int ldg = 0, chunks = 0;
-    DevBuf slab, G, maskd, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt, sol, wdev, partial, flag,
-        freeVar, maskTmp;
-    std::vector<double> hG, hScale;
-    // tableau
-    int n = 0, kbits = 0, T = 0;
-    bool use_reg = false;
-    double tol = 0.0;
-    unsigned long long last_pivots = 0;
-};
-
-static inline void t_begin(partls_ctx *c, int w) { (void)hipEventRecord(c->ev0[w], c->stream); }
-static inline void t_end(partls_ctx *c, int w) { (void)hipEventRecord(c->ev1[w], c->stream); c->timed[w] = true; }
-static void t_collect(partls_ctx *c)
+void t_begin(partls_ctx *c, int w) { (void)hipEventRecord(c->ev0[w], c->stream); }
+void t_end(partls_ctx *c, int w) { (void)hipEventRecord(c->ev1[w], c->stream); c->timed[w] = true; }
+void t_collect(partls_ctx *c)
 {
     for (int w = 0; w < PARTLS_T_COUNT; ++w)
         if (c->timed[w]) {
@@ -80,61 +33,7 @@ static void t_collect(partls_ctx *c)
         }
 }
 
-extern "C" {
-
-int partls_version(void) { return 100; }
-const char *partls_last_error(void) { return g_err; }
-
-int partls_device_count(void)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
-
-partls_status partls_create(int device, partls_ctx **out)
-{
-    if (!out) { set_error("partls_create: out is NULL"); return PARTLS_ERR_BAD_ARG; }
-    *out = nullptr;
-    int n = partls_device_count();
-    if (n <= 0 || device < 0 || device >= n) {
-        set_error("partls_create: no usable HIP device (count=%d, requested=%d); this library has no CPU fallback", n, device);
-        return PARTLS_ERR_NO_DEVICE;
-    }
-    PARTLS_HIP_CHECK(hipSetDevice(device));
-    partls_ctx *c = new (std::nothrow) partls_ctx();
-    if (!c) { set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
-    c->device = device;
-    PARTLS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int w = 0; w < PARTLS_T_COUNT; ++w) {
-        PARTLS_HIP_CHECK(hipEventCreate(&c->ev0[w]));
-        PARTLS_HIP_CHECK(hipEventCreate(&c->ev1[w]));
-    }
-    *out = c;
-    return PARTLS_OK;
-}
-
-void partls_destroy(partls_ctx *c)
-{
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskd, &c->scale, &c->Tfull, &c->T0reg, &c->scratch,
-                      &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->sol, &c->wdev, &c->partial, &c->flag,
-                      &c->freeVar, &c->maskTmp};
-    for (DevBuf *b : bufs) b->release();
-    for (int w = 0; w < PARTLS_T_COUNT; ++w) { (void)hipEventDestroy(c->ev0[w]); (void)hipEventDestroy(c->ev1[w]); }
-    (void)hipStreamDestroy(c->stream);
-    delete c;
-}
-
-}  // extern "C"
-
-// ---------------------------------------------------------------------------------------------------------------------
-// helpers
-// ---------------------------------------------------------------------------------------------------------------------
-static partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, int64_t ldX, const void *P, int64_t K,
-                                  int64_t ldP)
+partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, int64_t ldX, const void *P, int64_t K, int64_t ldP)
 {
     if (!c) { set_error("context is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (!X || !P) { set_error("X or P is NULL"); return PARTLS_ERR_BAD_ARG; }
@@ -161,71 +60,160 @@ static partls_status load_partition(partls_ctx *c, const int64_t *P, int64_t M, 
     return PARTLS_OK;
 }
 
-// regularised augmented Gram entry on the host copy (mirrors reg_entry in misc.hip)
-static double h_reg(const partls_ctx *c, int a, int b)
+double h_reg(const partls_ctx *c, int a, int b)
 {
     double v = c->hG[(size_t)a * c->ldg + b];
     if (c->eta != 0.0 && a <= c->M && b <= c->M) v += c->eta * (double)__builtin_popcountll(c->mask_aug[a] & c->mask_aug[b]);
     return v;
 }
 
-static uint64_t gray_inverse(uint64_t pat)
+partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int x_on_device,
+                          const int64_t *P, int64_t K, int64_t ldP, double eta, bool faithful, uint32_t flags)
 {
-    uint64_t g = pat;
-    for (int s = 1; s < 64; s <<= 1) g ^= g >> s;
-    return g;
+    partls_status st = check_common(c, X, N, M, ldX, P, K, ldP);
+    if (st != PARTLS_OK) return st;
+    if (!y) { set_error("y is NULL"); return PARTLS_ERR_BAD_ARG; }
+    if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
+    c->prepared = false;
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    st = load_partition(c, P, M, K, ldP);
+    if (st != PARTLS_OK) return st;
+    c->N = N; c->M = M; c->K = K; c->eta = eta; c->flags = flags; c->faithful = faithful;
+
+    if (x_on_device) {
+        c->dX = X; c->dy = y; c->ldX = ldX;
+    } else {
+        PARTLS_HIP_CHECK(c->ownX.ensure((size_t)N * M * sizeof(double)));
+        PARTLS_HIP_CHECK(c->ownY.ensure((size_t)N * sizeof(double)));
+        PARTLS_HIP_CHECK(hipMemcpy2DAsync(c->ownX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double),
+                                          (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->ownY.p, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->dX = c->ownX.as<double>(); c->dy = c->ownY.as<double>(); c->ldX = N;
+    }
+    PARTLS_HIP_CHECK(c->flag.ensure(sizeof(int)));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->flag.p, 0, sizeof(int), c->stream));
+    PARTLS_HIP_CHECK(launch_finite_check(c->dX, N, M, c->ldX, c->dy, c->flag.as<int>(), c->stream));
+
+    // Gram products (fp64 MFMA)
+    const size_t slabd = gram_slab_doubles(N, M, &c->chunks, &c->ldg);
+    PARTLS_HIP_CHECK(c->slab.ensure(slabd * sizeof(double)));
+    PARTLS_HIP_CHECK(c->G.ensure((size_t)c->ldg * c->ldg * sizeof(double)));
+    t_begin(c, PARTLS_T_GRAM);
+    PARTLS_HIP_CHECK(launch_gram(c->dX, N, M, c->ldX, c->dy, c->slab.as<double>(), c->chunks, c->ldg, c->G.as<double>(), c->stream));
+    t_end(c, PARTLS_T_GRAM);
+
+    // tableau variables, grouped by partition (stable sort on the lowest group a variable belongs to) so that the
+    // variables one Gray-code flip touches sit in as few 16-wide tile columns as possible
+    c->n = faithful ? (int)M + 1 : (int)M;
+    c->kbits = faithful ? (int)K + 1 : (int)K;
+    c->perm.resize((size_t)c->n);
+    std::iota(c->perm.begin(), c->perm.end(), 0);
+    auto key = [&](int v) { const uint64_t m = c->mask_aug[(size_t)v]; return m ? __builtin_ctzll(m) : 64; };
+    std::stable_sort(c->perm.begin(), c->perm.end(), [&](int a, int b) { return key(a) < key(b); });
+    c->mask_tab.resize((size_t)c->n);
+    for (int i = 0; i < c->n; ++i) c->mask_tab[(size_t)i] = c->mask_aug[(size_t)c->perm[(size_t)i]];
+
+    PARTLS_HIP_CHECK(c->maskAugD.ensure(((size_t)M + 2) * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(c->maskTabD.ensure((size_t)c->n * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(c->permD.ensure((size_t)c->n * sizeof(int)));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskAugD.p, c->mask_aug.data(), ((size_t)M + 2) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskTabD.p, c->mask_tab.data(), (size_t)c->n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->permD.p, c->perm.data(), (size_t)c->n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(c->scale.ensure((size_t)c->n * sizeof(double)));
+    PARTLS_HIP_CHECK(c->Tfull.ensure((size_t)(c->n + 1) * (c->n + 1) * sizeof(double)));
+    t_begin(c, PARTLS_T_PREP);
+    PARTLS_HIP_CHECK(launch_prep(c->G.as<double>(), c->ldg, (int)M, eta, c->maskAugD.as<uint64_t>(), faithful ? 0 : 1,
+                                 c->permD.as<int>(), c->scale.as<double>(), c->Tfull.as<double>(), c->n, c->stream));
+    c->use_reg = sweep_reg_supported(c->n) && !(flags & PARTLS_OPT_GENERIC_KERNEL);
+    if (c->use_reg) {
+        c->T = sweep_reg_tiles(c->n);
+        PARTLS_HIP_CHECK(c->T0reg.ensure(sweep_reg_t0_doubles(c->T) * sizeof(double)));
+        PARTLS_HIP_CHECK(launch_layout_reg(c->Tfull.as<double>(), c->n, c->T, c->T0reg.as<double>(), c->stream));
+    }
+    t_end(c, PARTLS_T_PREP);
+
+    c->hG.resize((size_t)c->ldg * c->ldg);
+    c->hScale.resize((size_t)c->n);
+    int bad = 0;
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->hG.data(), c->G.p, c->hG.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->hScale.data(), c->scale.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(&bad, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    t_collect(c);
+    if (bad) { set_error("X or y contains NaN/Inf"); return PARTLS_ERR_NONFINITE; }
+    const double yy = c->hG[(size_t)(M + 1) * c->ldg + (M + 1)];
+    const char *tolenv = getenv("PARTLS_TOL_REL");
+    const double tolrel = tolenv ? atof(tolenv) : 1e-11;
+    c->tol = tolrel * std::sqrt(yy > 0.0 ? yy : 0.0);
+    if (!(c->tol > 0.0)) c->tol = 1e-300;
+    c->prepared = true;
+    return PARTLS_OK;
 }
 
-// Solve ONE pattern with the global-memory kernel and fetch the scaled solution.  mask_dev/free_dev may override the
-// prepared masks (Alt zero-β groups, BnB free groups).  Tableau must be prepared.
-static partls_status solve_single(partls_ctx *c, uint64_t pattern, const uint64_t *mask_dev, const uint8_t *free_dev,
-                                  std::vector<double> &sol, double *obj2, unsigned long long *unconv)
+static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
+{
+    if (c->use_reg) {
+        p.T0 = c->T0reg.as<double>();
+        const char *kv = getenv("PARTLS_KERNEL");          // "reg" = rank-1 register kernel (A/B); default = blocked pivots
+        if (kv && strcmp(kv, "reg") == 0) return launch_sweep_reg(p, c->T, grid, c->stream);
+        return launch_sweep_blk(p, c->T, grid, c->stream);
+    }
+    p.T0 = c->Tfull.as<double>();
+    return launch_sweep_generic(p, grid, c->stream);
+}
+
+partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const std::vector<uint64_t> &free_,
+                          const std::vector<uint64_t> &zero, std::vector<double> &sols, std::vector<double> &obj2,
+                          unsigned long long *unconv)
 {
     const int n = c->n, ld = n + 1;
-    PARTLS_HIP_CHECK(c->scratch.ensure((size_t)ld * ld * sizeof(double)));
+    const size_t cnt = pat.size();
+    sols.assign(cnt * (size_t)n, 0.0);
+    obj2.assign(cnt, 0.0);
+    if (unconv) *unconv = 0;
+    if (cnt == 0) return PARTLS_OK;
+    const int grid = (int)std::min<size_t>(cnt, c->use_reg ? 2048 : 512);
+    PARTLS_HIP_CHECK(c->nodePat.ensure(cnt * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(c->nodeFree.ensure(cnt * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(c->nodeZero.ensure(cnt * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(c->nodeSol.ensure(cnt * (size_t)n * sizeof(double)));
+    PARTLS_HIP_CHECK(c->nodeObj.ensure(cnt * sizeof(double)));
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
     PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
-    PARTLS_HIP_CHECK(c->sol.ensure((size_t)(n + 1) * sizeof(double)));
+    if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
+    else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
     PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodePat.p, pat.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeFree.p, free_.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeZero.p, zero.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
-    p.mask = mask_dev ? mask_dev : c->maskd.as<uint64_t>();
-    p.T0 = c->Tfull.as<double>();
+    p.mask = c->maskTabD.as<uint64_t>();
     p.scratch = c->scratch.as<double>();
-    const uint64_t g = gray_inverse(pattern);
-    p.g_begin = (int64_t)g; p.g_end = (int64_t)g + 1; p.chain_len = 1;
+    p.g_begin = 0; p.g_end = (int64_t)cnt; p.chain_len = 1;
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
     p.all_opt = nullptr;
     p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
     p.n_unconverged = c->counters.as<unsigned long long>();
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
-    p.sol = c->sol.as<double>(); p.sol_obj2 = c->sol.as<double>() + n;
-    p.free_var = free_dev;
-    if (c->use_reg && !free_dev) {                      // register-resident kernel: ~n/2 pivots from the fresh tableau
-        p.T0 = c->T0reg.as<double>();
-        const char *kv = getenv("PARTLS_KERNEL");
-        if (kv && strcmp(kv, "reg") == 0) PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, 1, c->stream));
-        else PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, 1, c->stream));
-    } else {
-        PARTLS_HIP_CHECK(launch_sweep_generic(p, 1, c->stream));
-    }
-    sol.resize((size_t)n + 1);
-    unsigned long long cnt[2] = {0, 0};
-    PARTLS_HIP_CHECK(hipMemcpyAsync(sol.data(), c->sol.p, (size_t)(n + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    p.node_pat = c->nodePat.as<uint64_t>(); p.node_free = c->nodeFree.as<uint64_t>(); p.node_zero = c->nodeZero.as<uint64_t>();
+    p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
+    PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
+    unsigned long long counters[2] = {0, 0};
+    PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->nodeSol.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(obj2.data(), c->nodeObj.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (obj2) *obj2 = sol[(size_t)n];
-    if (unconv) *unconv = cnt[0];
+    if (unconv) *unconv = counters[0];
     return PARTLS_OK;
 }
 
-// scaled tableau solution -> w over [features, intercept] (length M+1), using the host Gram copy for a free intercept
-static void unscale_solution(const partls_ctx *c, const std::vector<double> &sol, std::vector<double> &w)
+void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w)
 {
     const int M = (int)c->M;
     w.assign((size_t)M + 1, 0.0);
-    for (int i = 0; i < c->n; ++i) w[(size_t)i] = sol[(size_t)i] * c->hScale[(size_t)i];
+    for (int i = 0; i < c->n; ++i) w[(size_t)c->perm[(size_t)i]] = sol[i] * c->hScale[(size_t)i];
     if (!c->faithful) {
         // intercept eliminated up front: t = (c_I - sum_f G_If w_f) / G_II   (row I of the normal equations)
         double s = h_reg(c, M, M + 1);
@@ -234,8 +222,7 @@ static void unscale_solution(const partls_ctx *c, const std::vector<double> &sol
     }
 }
 
-// ||Xo w - yo||_2 from the data (+ the η rows): Opt.jl:90
-static partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt)
+partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt)
 {
     const int64_t M = c->M;
     const int nb = 1024;
@@ -286,79 +273,62 @@ static void cleanup_opt(const partls_ctx *c, const std::vector<double> &w, uint6
     *t = w[(size_t)M];                                   // t = β[end]*α[end] = f_I α_I = w_I (Opt.jl:92)
 }
 
+}  // namespace partls
+
+using namespace partls;
+
 extern "C" {
+
+int partls_version(void) { return 100; }
+const char *partls_last_error(void) { return g_err; }
+
+int partls_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+partls_status partls_create(int device, partls_ctx **out)
+{
+    if (!out) { set_error("partls_create: out is NULL"); return PARTLS_ERR_BAD_ARG; }
+    *out = nullptr;
+    int n = partls_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        set_error("partls_create: no usable HIP device (count=%d, requested=%d); this library has no CPU fallback", n, device);
+        return PARTLS_ERR_NO_DEVICE;
+    }
+    PARTLS_HIP_CHECK(hipSetDevice(device));
+    partls_ctx *c = new (std::nothrow) partls_ctx();
+    if (!c) { set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+    c->device = device;
+    PARTLS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int w = 0; w < PARTLS_T_COUNT; ++w) {
+        PARTLS_HIP_CHECK(hipEventCreate(&c->ev0[w]));
+        PARTLS_HIP_CHECK(hipEventCreate(&c->ev1[w]));
+    }
+    *out = c;
+    return PARTLS_OK;
+}
+
+void partls_destroy(partls_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
+                      &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
+                      &c->flag, &c->nodePat, &c->nodeFree, &c->nodeZero, &c->nodeSol, &c->nodeObj};
+    for (DevBuf *b : bufs) b->release();
+    for (int w = 0; w < PARTLS_T_COUNT; ++w) { (void)hipEventDestroy(c->ev0[w]); (void)hipEventDestroy(c->ev1[w]); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
 
 partls_status partls_opt_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                                  int x_on_device, const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags)
 {
-    partls_status st = check_common(c, X, N, M, ldX, P, K, ldP);
-    if (st != PARTLS_OK) return st;
-    if (!y) { set_error("y is NULL"); return PARTLS_ERR_BAD_ARG; }
-    if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
-    c->prepared = false;
-    PARTLS_HIP_CHECK(hipSetDevice(c->device));
-    st = load_partition(c, P, M, K, ldP);
-    if (st != PARTLS_OK) return st;
-    c->N = N; c->M = M; c->K = K; c->eta = eta; c->flags = flags;
-    c->faithful = (flags & PARTLS_OPT_FAITHFUL_INTERCEPT) != 0;
-
-    if (x_on_device) {
-        c->dX = X; c->dy = y; c->ldX = ldX;
-    } else {
-        PARTLS_HIP_CHECK(c->ownX.ensure((size_t)N * M * sizeof(double)));
-        PARTLS_HIP_CHECK(c->ownY.ensure((size_t)N * sizeof(double)));
-        PARTLS_HIP_CHECK(hipMemcpy2DAsync(c->ownX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double),
-                                          (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, c->stream));
-        PARTLS_HIP_CHECK(hipMemcpyAsync(c->ownY.p, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        c->dX = c->ownX.as<double>(); c->dy = c->ownY.as<double>(); c->ldX = N;
-    }
-    // NaN / Inf screen
-    PARTLS_HIP_CHECK(c->flag.ensure(sizeof(int)));
-    PARTLS_HIP_CHECK(hipMemsetAsync(c->flag.p, 0, sizeof(int), c->stream));
-    PARTLS_HIP_CHECK(launch_finite_check(c->dX, N, M, c->ldX, c->dy, c->flag.as<int>(), c->stream));
-
-    // Gram products
-    const size_t slabd = gram_slab_doubles(N, M, &c->chunks, &c->ldg);
-    PARTLS_HIP_CHECK(c->slab.ensure(slabd * sizeof(double)));
-    PARTLS_HIP_CHECK(c->G.ensure((size_t)c->ldg * c->ldg * sizeof(double)));
-    t_begin(c, PARTLS_T_GRAM);
-    PARTLS_HIP_CHECK(launch_gram(c->dX, N, M, c->ldX, c->dy, c->slab.as<double>(), c->chunks, c->ldg, c->G.as<double>(), c->stream));
-    t_end(c, PARTLS_T_GRAM);
-
-    // tableau
-    c->n = c->faithful ? (int)M + 1 : (int)M;
-    c->kbits = c->faithful ? (int)K + 1 : (int)K;
-    PARTLS_HIP_CHECK(c->maskd.ensure(((size_t)M + 2) * sizeof(uint64_t)));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskd.p, c->mask_aug.data(), ((size_t)M + 2) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    PARTLS_HIP_CHECK(c->scale.ensure((size_t)c->n * sizeof(double)));
-    PARTLS_HIP_CHECK(c->Tfull.ensure((size_t)(c->n + 1) * (c->n + 1) * sizeof(double)));
-    t_begin(c, PARTLS_T_PREP);
-    PARTLS_HIP_CHECK(launch_prep(c->G.as<double>(), c->ldg, (int)M, eta, c->maskd.as<uint64_t>(), c->faithful ? 0 : 1,
-                                 c->scale.as<double>(), c->Tfull.as<double>(), c->n, c->stream));
-    c->use_reg = sweep_reg_supported(c->n) && !(flags & PARTLS_OPT_GENERIC_KERNEL);
-    if (c->use_reg) {
-        c->T = sweep_reg_tiles(c->n);
-        PARTLS_HIP_CHECK(c->T0reg.ensure(sweep_reg_t0_doubles(c->T) * sizeof(double)));
-        PARTLS_HIP_CHECK(launch_layout_reg(c->Tfull.as<double>(), c->n, c->T, c->T0reg.as<double>(), c->stream));
-    }
-    t_end(c, PARTLS_T_PREP);
-
-    c->hG.resize((size_t)c->ldg * c->ldg);
-    c->hScale.resize((size_t)c->n);
-    int bad = 0;
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->hG.data(), c->G.p, c->hG.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->hScale.data(), c->scale.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(&bad, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    t_collect(c);
-    if (bad) { set_error("X or y contains NaN/Inf"); return PARTLS_ERR_NONFINITE; }
-    const double yy = c->hG[(size_t)(M + 1) * c->ldg + (M + 1)];
-    const char *tolenv = getenv("PARTLS_TOL_REL");
-    const double tolrel = tolenv ? atof(tolenv) : 1e-11;
-    c->tol = tolrel * std::sqrt(yy > 0.0 ? yy : 0.0);
-    if (!(c->tol > 0.0)) c->tol = 1e-300;
-    c->prepared = true;
-    return PARTLS_OK;
+    return ctx_prepare(c, X, N, M, ldX, y, x_on_device, P, K, ldP, eta, (flags & PARTLS_OPT_FAITHFUL_INTERCEPT) != 0, flags);
 }
 
 int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared) ? ((int64_t)1 << c->kbits) : 0; }
@@ -400,8 +370,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
 
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
-    p.mask = c->maskd.as<uint64_t>();
-    p.T0 = c->use_reg ? c->T0reg.as<double>() : c->Tfull.as<double>();
+    p.mask = c->maskTabD.as<uint64_t>();
     p.scratch = c->scratch.as<double>();
     p.g_begin = g_begin; p.g_end = g_end; p.chain_len = chain_len;
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
@@ -409,14 +378,9 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
     p.n_unconverged = c->counters.as<unsigned long long>();
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
-    p.sol = nullptr; p.sol_obj2 = nullptr; p.free_var = nullptr;
 
     t_begin(c, PARTLS_T_SWEEP);
-    if (c->use_reg) {
-        const char *kv = getenv("PARTLS_KERNEL");          // "reg" = rank-1 register kernel (A/B), default = blocked pivots
-        if (kv && strcmp(kv, "reg") == 0) PARTLS_HIP_CHECK(launch_sweep_reg(p, c->T, grid, c->stream));
-        else PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, grid, c->stream));
-    } else PARTLS_HIP_CHECK(launch_sweep_generic(p, grid, c->stream));
+    PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
     t_end(c, PARTLS_T_SWEEP);
 
     std::vector<double> bo((size_t)grid);
@@ -458,12 +422,12 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     if (pattern < 0 || pattern >= ((int64_t)1 << (c->K + 1))) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     const uint64_t kmask = ((uint64_t)1 << c->kbits) - 1;
-    std::vector<double> sol, w;
+    std::vector<double> sols, obj2, w;
     unsigned long long unconv = 0;
     t_begin(c, PARTLS_T_FINISH);
-    partls_status st = solve_single(c, (uint64_t)pattern & kmask, nullptr, nullptr, sol, nullptr, &unconv);
+    partls_status st = solve_nodes(c, {(uint64_t)pattern & kmask}, {0}, {0}, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
-    unscale_solution(c, sol, w);
+    unscale_solution(c, sols.data(), w);
     uint64_t full = (uint64_t)pattern & kmask;
     if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
     else full = (uint64_t)pattern;
@@ -484,11 +448,11 @@ partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alp
     if (!c->faithful) { set_error("partls_opt_pattern needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (pattern < 0 || pattern >= ((int64_t)1 << c->kbits)) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
-    std::vector<double> sol, w;
+    std::vector<double> sols, obj2, w;
     unsigned long long unconv = 0;
-    partls_status st = solve_single(c, (uint64_t)pattern, nullptr, nullptr, sol, nullptr, &unconv);
+    partls_status st = solve_nodes(c, {(uint64_t)pattern}, {0}, {0}, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
-    unscale_solution(c, sol, w);
+    unscale_solution(c, sols.data(), w);
     if (optval) { st = data_objective(c, w, optval); if (st != PARTLS_OK) return st; }
     if (raw_alpha)
         for (int64_t m = 0; m <= c->M; ++m) {

@@ -40,12 +40,16 @@ struct SweepParams {
     int64_t *best_pat;           // [gridDim.x] its pattern index (lexicographic tie-break on the index)
     unsigned long long *n_unconverged;   // patterns that hit max_rounds
     unsigned long long *n_pivots;        // total pivots (diagnostics / flop accounting)
-    // single-pattern dump (finish / opt_pattern / Alt / BnB): when sol != nullptr the LAST pattern's rhs column and
-    // basis flags are written out: sol[n] = scaled solution (0 for nonbasic), and sol_obj2 = corner.
-    double *sol;
-    double *sol_obj2;
-    // BnB: per-variable state override; nullptr for Opt. state[i]: 0 = sign from pattern, 1 = free (always basic)
-    const uint8_t *free_var;
+    // Node mode (Alt alpha-steps, BnB node bounds): when node_pat != nullptr chain c is ONE subproblem with its own
+    // pattern node_pat[c], free groups node_free[c] (no sign constraint: BnB's relaxed groups, BnB.jl:70-79) and zero
+    // groups node_zero[c] (multiplier 0, e.g. beta_k == 0 in Alt.jl:80-81).  chain_len must be 1.  Outputs per node:
+    // node_sol[c * node_ld + v] = scaled solution (0 for nonbasic), node_obj2[c] = objective^2.
+    const uint64_t *node_pat;
+    const uint64_t *node_free;
+    const uint64_t *node_zero;
+    double *node_sol;
+    double *node_obj2;
+    int node_ld;
 };
 
 // launchers (each returns hipError_t of the launch)
@@ -63,8 +67,9 @@ hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const
                        int ldg, double *G, hipStream_t s);
 
 // tableau prep: B = regularised (and, free-intercept mode, intercept-eliminated) Gram; Tfull = unit-diagonal scaled
+// perm[i] = augmented-Gram index of tableau variable i (variables are grouped by partition so a flip touches few tiles)
 hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, int free_intercept,
-                       double *scale, double *Tfull, int n, hipStream_t s);
+                       const int *perm, double *scale, double *Tfull, int n, hipStream_t s);
 
 // residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
 hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *w, double t,

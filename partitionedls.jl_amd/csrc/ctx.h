@@ -1,0 +1,81 @@
+// ctx.h — the context behind the opaque partls_ctx handle and the host helpers shared by api.hip and solvers.hip.
+#pragma once
+#include "common.h"
+#include <vector>
+
+namespace partls {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t b)
+    {
+        if (b <= bytes && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, b ? b : 8);
+        if (e == hipSuccess) bytes = b;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace partls
+
+struct partls_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0[PARTLS_T_COUNT] = {}, ev1[PARTLS_T_COUNT] = {};
+    bool timed[PARTLS_T_COUNT] = {};
+    double ms[PARTLS_T_COUNT] = {};
+
+    // problem
+    bool prepared = false;
+    int64_t N = 0, M = 0, K = 0, ldX = 0;
+    double eta = 0.0;
+    uint32_t flags = 0;
+    bool faithful = false;                         // intercept is a sign-constrained tableau variable (2^(K+1) patterns)
+    const double *dX = nullptr, *dy = nullptr;     // device views (owned copies below, or the caller's)
+    partls::DevBuf ownX, ownY;
+    std::vector<int64_t> P;                        // M x K compact
+    std::vector<uint64_t> mask_aug;                // M + 2: features, intercept (bit K), y (0)
+    // gram
+    int ldg = 0, chunks = 0;
+    partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
+        wdev, partial, flag, nodePat, nodeFree, nodeZero, nodeSol, nodeObj;
+    std::vector<double> hG, hScale;
+    // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
+    int n = 0, kbits = 0, T = 0;
+    std::vector<int> perm;
+    std::vector<uint64_t> mask_tab;
+    bool use_reg = false;
+    double tol = 0.0;
+    unsigned long long last_pivots = 0;
+};
+
+namespace partls {
+
+void t_begin(partls_ctx *c, int w);
+void t_end(partls_ctx *c, int w);
+void t_collect(partls_ctx *c);
+
+// Upload (or adopt) X, y; build the Gram products; lay the tableau out.  faithful = intercept is a regular variable.
+partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int x_on_device,
+                          const int64_t *P, int64_t K, int64_t ldP, double eta, bool faithful, uint32_t flags);
+
+// Solve a batch of independent subproblems ("nodes") from the fresh tableau: node i has sign pattern pat[i] (bit k = sign
+// of group k), free groups free_[i] (no sign constraint) and zero groups zero[i] (multiplier 0).  sols: count x n scaled
+// solutions in tableau order (0 for nonbasic); obj2: objective^2 from the tableau corner.
+partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const std::vector<uint64_t> &free_,
+                          const std::vector<uint64_t> &zero, std::vector<double> &sols, std::vector<double> &obj2,
+                          unsigned long long *unconv);
+
+// scaled tableau solution -> w over [features, intercept] (length M+1); a free intercept is recovered from the Gram copy
+void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w);
+// ||Xo w - yo||_2 from the data (+ the eta rows): Opt.jl:90
+partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt);
+// regularised augmented Gram entry on the host copy
+double h_reg(const partls_ctx *c, int a, int b);
+partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, int64_t ldX, const void *P, int64_t K, int64_t ldP);
+
+}  // namespace partls

@@ -96,10 +96,10 @@ __device__ static inline double reg_entry(const double *G, int ldg, int M, doubl
 }
 
 __device__ static inline double base_entry(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug,
-                                           int free_intercept, int n, int i, int j)
+                                           int free_intercept, const int *perm, int n, int i, int j)
 {
-    // tableau index -> augmented Gram index: variables 0..n-1 then the rhs (y) at index n
-    const int a = (i < n) ? i : M + 1, b = (j < n) ? j : M + 1;
+    // tableau index -> augmented Gram index: variables perm[0..n-1] (grouped by partition) then the rhs (y) at index n
+    const int a = (i < n) ? perm[i] : M + 1, b = (j < n) ? perm[j] : M + 1;
     double v = reg_entry(G, ldg, M, eta, mask_aug, a, b);
     if (free_intercept) {
         const double gII = reg_entry(G, ldg, M, eta, mask_aug, M, M);
@@ -109,18 +109,20 @@ __device__ static inline double base_entry(const double *G, int ldg, int M, doub
 }
 
 __global__ void prep_scale_kernel(const double *__restrict__ G, int ldg, int M, double eta,
-                                  const uint64_t *__restrict__ mask_aug, int free_intercept, int n, double *__restrict__ scale)
+                                  const uint64_t *__restrict__ mask_aug, int free_intercept, const int *__restrict__ perm,
+                                  int n, double *__restrict__ scale)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double d = base_entry(G, ldg, M, eta, mask_aug, free_intercept, n, i, i);
-    const double ref = G[(size_t)i * ldg + i];
+    const double d = base_entry(G, ldg, M, eta, mask_aug, free_intercept, perm, n, i, i);
+    const double ref = G[(size_t)perm[i] * ldg + perm[i]];
     // a (numerically) null column carries no information: scale 0 keeps it out of every basis
     scale[i] = (d > 0.0 && d > 1e-14 * fabs(ref)) ? 1.0 / sqrt(d) : 0.0;
 }
 
 __global__ void prep_tableau_kernel(const double *__restrict__ G, int ldg, int M, double eta,
-                                    const uint64_t *__restrict__ mask_aug, int free_intercept, int n,
+                                    const uint64_t *__restrict__ mask_aug, int free_intercept,
+                                    const int *__restrict__ perm, int n,
                                     const double *__restrict__ scale, double *__restrict__ Tfull)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,21 +130,21 @@ __global__ void prep_tableau_kernel(const double *__restrict__ G, int ldg, int M
     if (idx >= ld * ld) return;
     const int i = idx / ld, j = idx % ld;
     const double si = (i < n) ? scale[i] : 1.0, sj = (j < n) ? scale[j] : 1.0;
-    double v = base_entry(G, ldg, M, eta, mask_aug, free_intercept, n, i, j) * si * sj;
+    double v = base_entry(G, ldg, M, eta, mask_aug, free_intercept, perm, n, i, j) * si * sj;
     if (i == j && i < n && si == 0.0) v = 1.0;          // dead variable: harmless unit pivot, never selected
     Tfull[idx] = v;
 }
 
 hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, int free_intercept,
-                       double *scale, double *Tfull, int n, hipStream_t s)
+                       const int *perm, double *scale, double *Tfull, int n, hipStream_t s)
 {
     hipLaunchKernelGGL(prep_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, s, G, ldg, M, eta, mask_aug,
-                       free_intercept, n, scale);
+                       free_intercept, perm, n, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int tot = (n + 1) * (n + 1);
     hipLaunchKernelGGL(prep_tableau_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, G, ldg, M, eta, mask_aug,
-                       free_intercept, n, scale, Tfull);
+                       free_intercept, perm, n, scale, Tfull);
     return hipGetLastError();
 }
 

@@ -213,8 +213,16 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
         STAMP(6);
 
         for (int64_t g = g0; g < g1; ++g) {
-            const uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
-            const int f = sign_of_var(vmask, pat);
+            uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            bool isfree = false;
+            int f;
+            if (p.node_pat) {                                       // node mode: chain index = node index
+                pat = p.node_pat[chain];
+                isfree = (vmask & p.node_free[chain]) != 0;
+                f = (vmask & p.node_zero[chain]) ? 0 : sign_of_var(vmask, pat);
+            } else {
+                f = sign_of_var(vmask, pat);
+            }
             blocked = false;
             int ninf_best = n + 1, patience = 3, rounds = 0;
             for (;;) {
@@ -224,7 +232,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                 bool bad = false;
                 if (has_var) {
                     const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
-                    if (basic) bad = (f == 0) || (fq < -p.tol);
+                    if (isfree) bad = !basic && !blocked && (fabs(q) > p.tol);     // free: stationarity only
+                    else if (basic) bad = (f == 0) || (fq < -p.tol);
                     else bad = (fq > p.tol) && !blocked;
                 }
                 const unsigned long long bb = __ballot(bad), bs = __ballot(basic);
@@ -334,9 +343,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
             if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
             if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
         }
-        if (p.sol) {
-            if (has_var) p.sol[tid] = basic ? q : 0.0;
-            if (tid == 0) *p.sol_obj2 = corner;
+        if (p.node_sol) {
+            if (has_var) p.node_sol[(size_t)chain * p.node_ld + tid] = basic ? q : 0.0;
+            if (tid == 0) p.node_obj2[chain] = corner;
         }
     }
     STAMP_FLUSH;

@@ -82,12 +82,11 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
         for (int idx = tid; idx < ld * ld; idx += GEN_THREADS) T[idx] = p.T0[idx];
         for (int i = tid; i < n; i += GEN_THREADS) { s_basic[i] = 0; s_blocked[i] = 0; }
         __syncthreads();
-        if (p.free_var)
-            for (int k = 0; k < n; ++k)
-                if (p.free_var[k]) { if (pivot(k)) ++npiv; }
 
         for (int64_t g = g0; g < g1; ++g) {
-            const uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            uint64_t gfree = 0, gzero = 0;
+            if (p.node_pat) { pat = p.node_pat[chain]; gfree = p.node_free[chain]; gzero = p.node_zero[chain]; }
             for (int i = tid; i < n; i += GEN_THREADS) s_blocked[i] = 0;
             __syncthreads();
             int ninf_best = n + 1, patience = 3, rounds = 0;
@@ -96,11 +95,13 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                 for (int base = 0; base < nwords * 64; base += GEN_THREADS) {
                     const int v = base + tid;
                     bool bad = false;
-                    if (v < n && !(p.free_var && p.free_var[v])) {
+                    if (v < n) {
                         const double q = T[(size_t)n * ld + v];
-                        const int f = sign_of_var(p.mask[v], pat);
+                        const uint64_t vm = p.mask[v];
+                        const int f = (vm & gzero) ? 0 : sign_of_var(vm, pat);
                         const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
-                        if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
+                        if (vm & gfree) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);   // free: stationarity only
+                        else if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
                         else bad = (fq > p.tol) && !s_blocked[v];
                     }
                     const unsigned long long b = __ballot(bad);
@@ -138,9 +139,10 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
             if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
             __syncthreads();
         }
-        if (p.sol) {                                               // single-pattern use: dump the last solution
-            for (int i = tid; i < n; i += GEN_THREADS) p.sol[i] = s_basic[i] ? T[(size_t)n * ld + i] : 0.0;
-            if (tid == 0) *p.sol_obj2 = T[(size_t)n * ld + n];
+        if (p.node_sol) {
+            for (int i = tid; i < n; i += GEN_THREADS)
+                p.node_sol[(size_t)chain * p.node_ld + i] = s_basic[i] ? T[(size_t)n * ld + i] : 0.0;
+            if (tid == 0) p.node_obj2[chain] = T[(size_t)n * ld + n];
         }
         __syncthreads();
     }
