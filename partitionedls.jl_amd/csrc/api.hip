@@ -397,10 +397,11 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     t_collect(c);
     c->last_pivots = cnt[1];
     if (getenv("PARTLS_PRINT_STAMPS")) {                 // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
-        double st[8];
+        double st[16];
         if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[partls stamps] scan %.0f gather %.0f panel %.0f update %.0f scatter %.0f chain-load %.0f/%.0f pivots %llu\n",
-                    st[0], st[1], st[2], st[3], st[4], st[5], st[6], cnt[1]);
+            fprintf(stderr, "[partls stamps] scan: pre %.0f barrier %.0f post %.0f | gather: work %.0f barrier %.0f | panel: work %.0f barrier %.0f | "
+                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu\n",
+                    st[9], st[10], st[0], st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1]);
     }
     double bobj = INFINITY;
     int64_t bpat = -1;

@@ -14,16 +14,14 @@
 //   4. scatter  : rows/columns of the pivoted variables are overwritten from the final panel (one if-chain per tile).
 // Layout of the register tableau, thread grid, half split and LDS image are those of sweep_reg.hip.
 #include "common.h"
+#include <type_traits>
 
 namespace partls {
 namespace blk {
 
 static constexpr int THREADS = 512;
 static constexpr int MAXT = 17;                 // n <= 272
-#ifndef PARTLS_MB
-#define PARTLS_MB 8
-#endif
-static constexpr int MB = PARTLS_MB;            // pivots per block (8: a tile column with more violators takes two blocks)
+static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks)
 
 constexpr int nslots(int T) { return T * (T + 1) / 2; }
 constexpr int tri(int g) { return g * (g + 1) / 2; }
@@ -38,9 +36,9 @@ constexpr int split(int T)
     return T == 1 ? 1 : best;
 }
 constexpr int rstride(int T) { return (T % 2) ? T : T + 1; }      // odd row stride: 16 lanes x 8 B hit 32 distinct banks
-constexpr int colw(int T) { return 16 * rstride(T) + 1; }          // panel column: 16*RS row positions + rhs row (odd)
-// LDS doubles: P[2][MB][COLW], Z[MB][COLW], U[2][MB], Dinv[MB]; then 32 x u64 masks
-constexpr int lds_doubles(int T) { return 3 * MB * colw(T) + 2 * MB + MB; }
+constexpr int colw(int T) { return 513; }                          // panel column: one slot per thread (16*RS rows + rhs + dummies), odd
+// LDS doubles: P[2][MB][COLW], Z[MB][COLW], U[2][MB+64], Dinv[MB+64] (64 per-lane dummy slots each); then 32 x u64 masks
+constexpr int lds_doubles(int T) { return 3 * MB * colw(T) + 3 * (MB + 64); }
 
 __device__ __forceinline__ double fast_rcp(double d)
 {
@@ -54,10 +52,10 @@ __device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat) { return 2 
 // Diagnostic build only (-DPARTLS_STAMPS): per-phase cycle shares of workgroup 0 / thread 0, written to p.scratch[0..7]
 // (a buffer no other code of the kernel reads).  Never quote this build's run time (cdna_hip_programming.md §7).
 #ifdef PARTLS_STAMPS
-#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP_DECL unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
 #define STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _n = __builtin_amdgcn_s_memtime(); \
                        st_acc[ph] += _n - st_t; st_t = _n; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_FLUSH do { if (tid == 0 && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 8; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
+#define STAMP_FLUSH do { if (tid == 0 && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 16; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(ph) do { } while (0)
@@ -117,51 +115,65 @@ __device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int 
     }
 }
 
-// ---- panel elimination for a block of m <= M pivots (M in {1,2,4,8}); straight-line inside a step ------------------------
-// Thread t owns row position t of the m (compacted) pivot columns in registers pv[0..M).  Step s: the pivot-row threads
-// publish their entry of column s through U, the thread that is pivot row s also publishes 1/d (or 0 for a dependent
-// column, Lawson–Hanson's rejection), one barrier, one batch of broadcast reads, then every thread updates its own row.
-template <int M, int RS, int CW>
-__device__ __forceinline__ void panel_block(double *P, double *Z, double *U, double *Dinv, int m, int myj, bool my_basic,
+// ---- panel elimination for a block of exactly M pivots (M = 1..MB); straight-line code, no guards ------------------------
+// Thread t owns row position t of the M (compacted) pivot columns in registers pv[0..M) (positions beyond the rhs row are
+// dummies: computed, stored, never read).  Step s: the pivot-row threads publish their entry of column s through U, the
+// thread that IS pivot row s also publishes 1/d (0 for a dependent column, Lawson–Hanson's rejection) — both as
+// unconditional stores, non-owners hit a dummy slot — one barrier, one batch of broadcast reads, then every thread
+// updates its own row.
+template <int M, int CW>
+__device__ __forceinline__ void panel_block(double *P, double *Z, double *U, double *Dinv, int myj, bool my_basic,
                                             double piv_eps, int tid)
 {
-    constexpr int RHSPOS = 16 * RS;
-    const bool rowok = tid <= RHSPOS;
+    constexpr int US = MB + 64;                             // U row stride; slots MB.. are per-lane dummies (no same-address stores)
+    const int dummy = MB + (tid & 63);
     double pv[M];
 #pragma unroll
-    for (int j = 0; j < M; ++j) pv[j] = P[(j < m ? j : 0) * CW + tid];        // j >= m: dummy copy of column 0, never stored
+    for (int j = 0; j < M; ++j) pv[j] = P[j * CW + tid];
+    const int uslot = myj >= 0 ? myj : dummy;
 #pragma unroll
     for (int s = 0; s < M; ++s) {
-        if (s < m) {
-            if (rowok) Z[s * CW + tid] = pv[s];
-            if (myj >= 0) U[(s & 1) * MB + myj] = pv[s];
-            if (myj == s) {
-                const double d = pv[s];
-                Dinv[s] = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
-            }
-            __syncthreads();
-            const double inv = Dinv[s], ainv = fabs(inv);
-            double u[M];
-#pragma unroll
-            for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * MB + j];
-            const bool ok = inv != 0.0, isrow = (myj == s);
-            const double fz = pv[s] * inv;
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                if (j == s) continue;
-                const double upd = isrow ? u[j] * ainv : fma(-fz, u[j], pv[j]);
-                pv[j] = ok ? upd : pv[j];
-            }
-            pv[s] = ok ? (isrow ? -inv : pv[s] * ainv) : pv[s];
+        Z[s * CW + tid] = pv[s];
+        U[(s & 1) * US + uslot] = pv[s];
+        {
+            const double d = pv[s];
+            const double r = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
+            Dinv[myj == s ? s : dummy] = r;
         }
-    }
-    if (rowok) {
+        __syncthreads();
+        const double inv = Dinv[s], ainv = fabs(inv);
+        double u[M];
 #pragma unroll
-        for (int j = 0; j < M; ++j)
-            if (j < m) P[j * CW + tid] = pv[j];
+        for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
+        const bool ok = inv != 0.0, isrow = (myj == s);
+        const double fz = pv[s] * inv;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            if (j == s) continue;
+            const double upd = isrow ? u[j] * ainv : fma(-fz, u[j], pv[j]);
+            pv[j] = ok ? upd : pv[j];
+        }
+        pv[s] = ok ? (isrow ? -inv : pv[s] * ainv) : pv[s];
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) P[j * CW + tid] = pv[j];
+}
+
+// wave-uniform dispatch on the tile index as a binary decision tree: ~log2(T) scalar branches, two-input joins only
+template <int LO, int HI, class F>
+__device__ __forceinline__ void tile_dispatch(int kappa, F &&f)
+{
+    if constexpr (HI - LO == 1) {
+        f(std::integral_constant<int, LO>{});
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (kappa < MID) tile_dispatch<LO, MID>(kappa, f);
+        else tile_dispatch<MID, HI>(kappa, f);
     }
 }
 
+#define PARTLS_CASES_LO(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+#define PARTLS_CASES_HI(M) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
 #define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
 
 template <int T, int H>
@@ -175,9 +187,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
 
     double *Pbase = lds;                                  // [2][MB][CW]
     double *Z = lds + 2 * MB * CW;                        // [MB][CW]
-    double *U = Z + MB * CW;                              // [2][MB]
-    double *Dinv = U + 2 * MB;                            // [MB]
-    unsigned long long *s_inf = reinterpret_cast<unsigned long long *>(Dinv + MB);   // [2][8]
+    double *U = Z + MB * CW;                              // [2][MB+64]
+    double *Dinv = U + 2 * (MB + 64);                     // [MB+64]
+    unsigned long long *s_inf = reinterpret_cast<unsigned long long *>(Dinv + MB + 64);  // [2][8]
     unsigned long long *s_bas = s_inf + 16;                                            // [2][8]
 
     for (int i = tid; i < lds_doubles(T) + 32; i += THREADS) lds[i] = 0.0;            // padding rows are never gathered
@@ -238,7 +250,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                 }
                 const unsigned long long bb = __ballot(bad), bs = __ballot(basic);
                 if (lane == 0 && wave < nwords) { s_inf[par * 8 + wave] = bb; s_bas[par * 8 + wave] = bs; }
+                STAMP(9);
                 __syncthreads();
+                STAMP(10);
                 // mask words are read once, reduced to (count, tile mask, largest violator) and dropped
                 int count = 0, single_k = -1;
                 unsigned tiles = 0;
@@ -281,8 +295,8 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         double *P = Pbase + (bc & 1) * MB * CW;
                         ++bc;
                         // ---- 1. gather the pivot columns (compacted) into the LDS panel ------------------------------------
-#define PARTLS_G(i) if constexpr (i < T) { if (kappa == i) gather_tile<T, H, i>(S, P, a, b, pm); }
-                        PARTLS_CASES(PARTLS_G)
+#define PARTLS_G(i) if constexpr (i < T) { if (__builtin_expect(kappa == i, 0)) gather_tile<T, H, i>(S, P, a, b, pm); }
+                        PARTLS_CASES(PARTLS_G)                 // flat chain of independent ifs: the only form the register allocator keeps spill-free
 #undef PARTLS_G
                         if (tid < 16 * T && (tid >> 4) == kappa && ((pm >> (tid & 15)) & 1u))
                             P[__builtin_popcount(pm & ((1u << (tid & 15)) - 1u)) * CW + RHSPOS] = q;
@@ -293,14 +307,21 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                             myj = __builtin_popcount(pm & ((1u << rowc) - 1u));
                             my_basic = (basm >> rowc) & 1u;
                         }
+                        STAMP(8);
                         __syncthreads();
                         STAMP(1);
                         // ---- 2. panel elimination -----------------------------------------------------------------------
-                        if (m == 1) panel_block<1, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
-                        else if (m == 2) panel_block<2, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
-                        else if (m <= 4) panel_block<4, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
-                        else if (m <= 8 || MB == 8) panel_block<8, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
-                        else panel_block<MB, RS, CW>(P, Z, U, Dinv, m, myj, my_basic, p.piv_eps, tid);
+                        switch (m) {
+                            case 1: panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 2: panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 3: panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 4: panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 5: panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 6: panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 7: panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            default: panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                        }
+                        STAMP(11);
                         __syncthreads();
                         STAMP(2);
                         // ---- 3. fused rank-m update of the register tableau ------------------------------------------------
@@ -324,7 +345,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         }
                         STAMP(3);
                         // ---- 4. rows / columns of the pivoted variables come from the final panel ----------------------------
-#define PARTLS_F(i) if constexpr (i < T) { if (kappa == i) scatter_tile<T, H, i>(S, P, a, b, pm); }
+#define PARTLS_F(i) if constexpr (i < T) { if (__builtin_expect(kappa == i, 0)) scatter_tile<T, H, i>(S, P, a, b, pm); }
                         PARTLS_CASES(PARTLS_F)
 #undef PARTLS_F
                         if (tid < 16 * T && (tid >> 4) == kappa && ((pm >> (tid & 15)) & 1u)) {
