@@ -80,11 +80,12 @@ def main():
         g0, g1 = pls.dist.shard_range(npat, rank, world)
         bobj, bpat, _, unconv = ctx.opt_sweep(g0, g1)
         t_gram, t_prep, t_sweep = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP)
+        pivots = ctx.pivots()
         # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
         _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=dev)
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         return dict(npat=npat, local=g1 - g0, opt=opt, best_index=bi, unconv=unconv, t_gram=t_gram, t_prep=t_prep,
-                    t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), alpha=a, beta=b, t=t)
+                    t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), alpha=a, beta=b, t=t, pivots=pivots)
 
     def barrier():
         if world > 1:
@@ -116,7 +117,15 @@ def main():
     solves_per_launch = res["local"]
     bytes_per_solve = algorithmic_bytes_per_solve(Mp)
     achieved_gbs = solves_per_launch * bytes_per_solve / sweep_avg_s / 1e9
-    # fp64 view of the same kernel: FMAs actually issued = pivots * stored tile slots * 256 lanes
+    # fp64 view of the same kernel: every pivot is one rank-1 update of the symmetric tableau = T(T+1)/2 tile slots x 256 FMAs
+    n_tab = Mp if args.faithful else D
+    tiles = (n_tab + 15) // 16
+    flops = res["pivots"] * (tiles * (tiles + 1) // 2) * 256 * 2
+    fp64_tflops = flops / sweep_avg_s / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")
+    if world == 1 and args.config == "C3" and not args.faithful and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]       # rocprofv3 PMC, measured offline on this kernel
     out = {
         "metric": "sign-pattern NNLS solves/sec (whole node); fp64 obj gap vs ref",
         "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -126,9 +135,12 @@ def main():
                                f"({'2^(K+1) faithful' if args.faithful else '2^K, free intercept'}), eta=0",
                    "seed": seed, "sharding": f"gray-index range / {world} ranks"},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "sweep_reg_kernel", "kernel_ms": sweep_avg_s * 1e3,
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3,
                      "algorithmic_bytes_per_solve": bytes_per_solve, "solves_per_launch": solves_per_launch},
+        "roofline_fp64": {"bound": "fp64 vector FMA", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": fp64_tflops / FP64_PEAK_TFLOPS, "pivots_per_launch": res["pivots"],
+                          "note": "the tableau is register-resident, so the kernel's real bound is fp64 FMA issue, not HBM"},
         "kernels_ms": {"gram_build": sum(gram_ms) / len(gram_ms), "prep": res["t_prep"], "sweep": sweep_avg_s * 1e3,
                        "finish": res["t_finish"]},
         "result": {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"]},

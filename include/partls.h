@@ -117,6 +117,8 @@ typedef enum {
     PARTLS_T_COUNT = 4
 } partls_timer;
 partls_status partls_get_timing(const partls_ctx *ctx, partls_timer which, double *ms);
+/* principal pivots executed by the last partls_opt_sweep (fp64 flop accounting: each pivot updates the whole symmetric tableau) */
+partls_status partls_get_pivots(const partls_ctx *ctx, int64_t *pivots);
 /* debugging / tests: copy the Gram products of the prepared problem to the host: G ((M+2) x (M+2), column-major,
  * variables ordered [features, intercept, y]), i.e. G, c = G[:, M+1], yy = G[M+1, M+1], after η has been applied. */
 partls_status partls_get_gram(const partls_ctx *ctx, double *G_aug);

@@ -143,6 +143,11 @@ class Context:
         _check(L.lib().partls_get_timing(self._h, int(which), C.byref(ms)))
         return ms.value
 
+    def pivots(self):
+        n = C.c_int64()
+        _check(L.lib().partls_get_pivots(self._h, C.byref(n)))
+        return n.value
+
     def gram(self):
         N, M, K = self._shape
         G = np.zeros((M + 2, M + 2), order="F")

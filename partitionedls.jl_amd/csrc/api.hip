@@ -557,6 +557,13 @@ partls_status partls_get_timing(const partls_ctx *c, partls_timer which, double 
     return PARTLS_OK;
 }
 
+partls_status partls_get_pivots(const partls_ctx *c, int64_t *pivots)
+{
+    if (!c || !pivots) { set_error("partls_get_pivots: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *pivots = (int64_t)c->last_pivots;
+    return PARTLS_OK;
+}
+
 partls_status partls_get_gram(const partls_ctx *c, double *G_aug)
 {
     if (!c || !c->prepared || !G_aug) { set_error("partls_get_gram: context not prepared"); return PARTLS_ERR_STATE; }

@@ -21,6 +21,9 @@ namespace blk {
 
 static constexpr int THREADS = 512;
 static constexpr int MAXT = 17;                 // n <= 272
+#ifndef PARTLS_UPD_UNROLL
+#define PARTLS_UPD_UNROLL 1
+#endif
 static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks)
 
 constexpr int nslots(int T) { return T * (T + 1) / 2; }
@@ -122,9 +125,10 @@ __device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int 
 // unconditional stores, non-owners hit a dummy slot — one barrier, one batch of broadcast reads, then every thread
 // updates its own row.
 template <int M, int CW>
-__device__ __forceinline__ void panel_block(double *P, double *Z, double *U, double *Dinv, int myj, bool my_basic,
+__device__ __forceinline__ bool panel_block(double *P, double *Z, double *U, double *Dinv, int myj, bool my_basic,
                                             double piv_eps, int tid)
 {
+    bool any_ok = false;                                    // uniform: was any pivot of the block carried out?
     constexpr int US = MB + 64;                             // U row stride; slots MB.. are per-lane dummies (no same-address stores)
     const int dummy = MB + (tid & 63);
     double pv[M];
@@ -146,6 +150,7 @@ __device__ __forceinline__ void panel_block(double *P, double *Z, double *U, dou
 #pragma unroll
         for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
         const bool ok = inv != 0.0, isrow = (myj == s);
+        any_ok = any_ok || ok;
         const double fz = pv[s] * inv;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -157,6 +162,7 @@ __device__ __forceinline__ void panel_block(double *P, double *Z, double *U, dou
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) P[j * CW + tid] = pv[j];
+    return any_ok;
 }
 
 // wave-uniform dispatch on the tile index as a binary decision tree: ~log2(T) scalar branches, two-input joins only
@@ -237,8 +243,13 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
             }
             blocked = false;
             int ninf_best = n + 1, patience = 3, rounds = 0;
+            bool progress = false;                                    // did the previous round change the basis?
             for (;;) {
                 // ---- KKT scan of the rhs column (registers) ------------------------------------------------------------
+                // a column rejected as dependent is only dependent on the basis it was tested against (Lawson–Hanson
+                // re-examines it after any exchange): forget the rejections once the basis has changed
+                if (progress) blocked = false;
+                progress = false;
                 const int par = sc & 1;
                 ++sc;
                 bool bad = false;
@@ -311,21 +322,22 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         __syncthreads();
                         STAMP(1);
                         // ---- 2. panel elimination -----------------------------------------------------------------------
+                        bool blk_ok = false;
                         switch (m) {
-                            case 1: panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            case 2: panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            case 3: panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            case 4: panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            case 5: panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            case 6: panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            case 7: panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
-                            default: panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 1: blk_ok = panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 2: blk_ok = panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 3: blk_ok = panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 4: blk_ok = panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 5: blk_ok = panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 6: blk_ok = panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            case 7: blk_ok = panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
+                            default: blk_ok = panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid); break;
                         }
                         STAMP(11);
                         __syncthreads();
                         STAMP(2);
                         // ---- 3. fused rank-m update of the register tableau ------------------------------------------------
-#pragma unroll 1
+#pragma unroll PARTLS_UPD_UNROLL
                         for (int s = 0; s < m; ++s) {
                             const double inv = Dinv[s];
                             const double *Zs = Z + s * CW;
@@ -354,6 +366,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                             if (Dinv[j] != 0.0) basic = !basic;
                             else blocked = true;
                         }
+                        progress = progress || blk_ok;
                         npiv += (unsigned)m;
                         STAMP(4);
                     }

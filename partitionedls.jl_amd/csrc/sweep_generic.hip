@@ -90,7 +90,13 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
             for (int i = tid; i < n; i += GEN_THREADS) s_blocked[i] = 0;
             __syncthreads();
             int ninf_best = n + 1, patience = 3, rounds = 0;
+            bool progress = false;
             for (;;) {
+                if (progress) {                                    // rejections hold for the basis they were tested against only
+                    for (int i = tid; i < n; i += GEN_THREADS) s_blocked[i] = 0;
+                    __syncthreads();
+                }
+                progress = false;
                 // ---- KKT scan of the rhs column -----------------------------------------------------------------
                 for (int base = 0; base < nwords * 64; base += GEN_THREADS) {
                     const int v = base + tid;
@@ -122,14 +128,14 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                         while (bits) {
                             const int k = (w << 6) + __builtin_ctzll(bits);
                             bits &= bits - 1;
-                            if (pivot(k)) ++npiv;
+                            if (pivot(k)) { ++npiv; progress = true; }
                         }
                     }
                 } else {
                     int k = -1;
                     for (int w = nwords - 1; w >= 0 && k < 0; --w)
                         if (s_inf[w]) k = (w << 6) + 63 - __builtin_clzll(s_inf[w]);
-                    if (pivot(k)) ++npiv;
+                    if (pivot(k)) { ++npiv; progress = true; }
                 }
                 __syncthreads();
             }

@@ -161,7 +161,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
             }
             blocked = false;
             int ninf_best = n + 1, patience = 3, rounds = 0;
+            bool progress = false;
             for (;;) {
+                if (progress) blocked = false;                 // rejections hold for the basis they were tested against only
+                progress = false;
                 // ---- KKT scan of the rhs column (registers) ------------------------------------------------------------
                 const int par = sc & 1;
                 ++sc;
@@ -239,6 +242,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                     PARTLS_CASES(PARTLS_F)
 #undef PARTLS_F
                     if (tid == k) basic = !basic;
+                    progress = true;
                     ++npiv;
                     if (!all) break;
                 }

@@ -1,0 +1,107 @@
+"""GPU edge cases (the reference tests none of these; the oracle is the checker).  Where the minimiser is not unique
+(rank-deficient designs) only the objective is compared — parity is on the optimum of each convex subproblem."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _check(partls, oracle, X, y, P, eta=0.0, model=True, algs=("Opt", "BnB")):
+    ref = oracle.fit_opt(X, y, P, eta=eta, return_all=True)
+    for name in algs:
+        alg = getattr(partls, name)
+        for faithful in ((True, False) if name == "Opt" else (False,)):
+            kw = dict(faithful_intercept=faithful) if name == "Opt" else {}
+            m, _, rep = partls.fit(alg, X, y, P, η=eta, **kw)
+            assert abs(rep.opt - ref["opt"]) <= TOL * max(1.0, ref["opt"]), (name, faithful, rep.opt, ref["opt"])
+            yhat = partls.predict(m, X)
+            if model:
+                np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-7)
+                np.testing.assert_allclose(m.β, ref["beta"], atol=1e-7)
+            # the fitted function reproduces the objective (η = 0): ||ŷ - y|| == opt
+            if eta == 0.0 and np.all(np.isfinite(yhat)):
+                assert abs(np.linalg.norm(yhat - y) - ref["opt"]) <= 1e-7 * max(1.0, ref["opt"])
+    return ref
+
+
+def test_single_group_is_plain_least_squares_with_sign(partls, oracle):
+    """MLJ's empty-P fallback (PartitionedLS.jl:318-322): one all-ones group."""
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((200, 6)); y = X @ np.array([1., 2, 0.5, 0.1, 3, 1]) + 0.3 + 0.05 * rng.standard_normal(200)
+    _check(partls, oracle, X, y, np.ones((6, 1), dtype=np.int64))
+
+
+def test_one_feature(partls, oracle):
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((50, 1)); y = -2.0 * X[:, 0] + 1.0
+    _check(partls, oracle, X, y, np.ones((1, 1), dtype=np.int64))
+
+
+def test_every_feature_its_own_group(partls, oracle):
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((300, 7)); y = X @ rng.standard_normal(7) - 0.7 + 0.1 * rng.standard_normal(300)
+    ref = _check(partls, oracle, X, y, np.eye(7, dtype=np.int64))
+    # with singleton groups the optimum is the unconstrained least-squares fit
+    Xo = np.hstack([X, np.ones((300, 1))])
+    assert abs(ref["opt"] - np.linalg.norm(Xo @ np.linalg.lstsq(Xo, y, rcond=None)[0] - y)) < 1e-9
+
+
+def test_underdetermined_rank_deficient(partls, oracle):
+    """N < M+1: the Gram matrix is singular; objective parity only (minimiser not unique)."""
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((8, 12)); y = rng.standard_normal(8)
+    P = np.zeros((12, 3), dtype=np.int64); P[np.arange(12), np.arange(12) % 3] = 1
+    _check(partls, oracle, X, y, P, model=False)
+
+
+def test_duplicate_and_zero_columns(partls, oracle):
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((120, 8))
+    X[:, 3] = X[:, 1]            # exact duplicate inside one group
+    X[:, 6] = 0.0                # null feature
+    y = X @ np.array([1., 1, -2, 1, -1, 0.5, 9, 2]) + 0.2 + 0.1 * rng.standard_normal(120)
+    P = np.zeros((8, 2), dtype=np.int64); P[:4, 0] = 1; P[4:, 1] = 1
+    _check(partls, oracle, X, y, P, model=False)
+
+
+def test_empty_group_and_unassigned_feature(partls, oracle):
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((150, 5)); y = X[:, 0] - X[:, 3] + 0.1 * rng.standard_normal(150)
+    P = np.zeros((5, 3), dtype=np.int64); P[0, 0] = P[1, 0] = 1; P[3, 2] = P[4, 2] = 1     # group 1 empty, feature 2 in no group
+    _check(partls, oracle, X, y, P, algs=("Opt",))
+
+
+def test_zero_target(partls, oracle):
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((60, 4)); y = np.zeros(60)
+    P = np.array([[1, 0], [1, 0], [0, 1], [0, 1]], dtype=np.int64)
+    m, _, rep = partls.fit(partls.Opt, X, y, P)
+    assert rep.opt == 0.0 and np.all(m.β == 0.0) and m.t == 0.0
+
+
+@pytest.mark.parametrize("eta", [1e-3, 10.0, 1e4])
+def test_regularisation_strengths(partls, oracle, eta):
+    X, y, P, _ = oracle.synth(20260130, 400, 15, 3)
+    _check(partls, oracle, X, y, P, eta=eta)
+
+
+def test_badly_scaled_columns(partls, oracle):
+    """columns differing by 1e6 in scale: the unit-diagonal scaling of the tableau absorbs it"""
+    X, y, P, _ = oracle.synth(20260131, 500, 12, 3)
+    X = np.asfortranarray(X * np.logspace(-3, 3, 12)[None, :])
+    _check(partls, oracle, X, y, P)
+
+
+def test_wide_tableau_boundary_sizes(partls, oracle):
+    """n around the 16-wide tile boundaries of the register kernel (n = M or M+1)"""
+    for M, K in [(15, 3), (16, 4), (17, 4), (31, 5), (32, 4), (33, 3)]:
+        X, y, P, _ = oracle.synth(20260140 + M, 600, M, K)
+        Xo, Po = oracle.homogeneous(X, P)
+        R, z = oracle.compress(Xo, y)
+        ref = oracle.opt_patterns(R, z, Po, np.arange(1 << (K + 1)))
+        ctx = partls.default_context()
+        ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+        bo, bp, allopt, unconv = ctx.opt_sweep(0, -1, want_all=True)
+        assert unconv == 0
+        np.testing.assert_allclose(allopt, ref, rtol=1e-10, atol=1e-10)
