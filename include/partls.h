@@ -90,6 +90,12 @@ partls_status partls_fit_alt(partls_ctx *ctx, const double *X, int64_t N, int64_
                              const double *alpha0, const double *beta0,
                              double *alpha, double *beta, double *t, double *opt, int64_t *iters);
 
+/* The same on a context already prepared with partls_opt_prepare(..., flags | PARTLS_OPT_FAITHFUL_INTERCEPT) — e.g. with
+ * device-resident inputs; partls_fit_alt / partls_fit_bnb are "prepare from host pointers" + these. */
+partls_status partls_alt_prepared(partls_ctx *ctx, double eps, int64_t T, const double *alpha0, const double *beta0,
+                                  double *alpha, double *beta, double *t, double *opt, int64_t *iters);
+partls_status partls_bnb_prepared(partls_ctx *ctx, double *alpha, double *beta, double *t, double *opt, int64_t *nopen);
+
 /* ---- fit(BnB, X, y, P; η)  — replaces BnB.jl:30-132 -------------------------------------------------------------------
  * Outputs as BnB.jl:36-40; *nopen = nodes bounded (search order differs from the reference's DFS, so it is not a
  * parity quantity). */

@@ -35,6 +35,8 @@ SYMBOLS = [
                                  C.c_double, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     ("partls_fit_bnb", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
                                  _dp, _dp, _dp, _dp, _ip]),
+    ("partls_alt_prepared", C.c_int, [C.c_void_p, C.c_double, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    ("partls_bnb_prepared", C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
     ("partls_predict", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, _i64, _i64, _dp, _dp, C.c_double, _dp]),
     ("partls_synth_truth", C.c_int, [C.c_uint64, _i64, _i64, _ip, _dp]),
     ("partls_synth_device", C.c_int, [C.c_void_p, C.c_uint64, _i64, _i64, _dp, C.c_void_p, C.c_void_p]),

@@ -138,6 +138,23 @@ class Context:
         _check(L.lib().partls_opt_pattern(self._h, int(pattern), _dp(ra), C.byref(o)))
         return ra, o.value
 
+    def alt_prepared(self, alpha0, beta0, eps=1e-6, T=100):
+        """Alt on a context prepared with OPT_FAITHFUL_INTERCEPT (e.g. device-resident inputs)."""
+        N, M, K = self._shape
+        a0 = np.ascontiguousarray(alpha0, dtype=np.float64); b0 = np.ascontiguousarray(beta0, dtype=np.float64)
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double(); it = C.c_int64()
+        _check(L.lib().partls_alt_prepared(self._h, float(eps), int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t),
+                                           C.byref(o), C.byref(it)))
+        return a, b, t.value, o.value, it.value
+
+    def bnb_prepared(self):
+        N, M, K = self._shape
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double(); no = C.c_int64()
+        _check(L.lib().partls_bnb_prepared(self._h, _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
+        return a, b, t.value, o.value, no.value
+
     def timing(self, which):
         ms = C.c_double()
         _check(L.lib().partls_get_timing(self._h, int(which), C.byref(ms)))

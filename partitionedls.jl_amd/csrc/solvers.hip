@@ -78,10 +78,20 @@ partls_status partls_fit_alt(partls_ctx *c, const double *X, int64_t N, int64_t 
                              const double *alpha0, const double *beta0,
                              double *alpha, double *beta, double *t, double *opt, int64_t *iters)
 {
-    if (!alpha0 || !beta0 || !alpha || !beta || !t || !opt) { set_error("partls_fit_alt: NULL argument"); return PARTLS_ERR_BAD_ARG; }
-    if (!(eps > 0.0) || T < 1) { set_error("partls_fit_alt: need eps > 0 and T >= 1 (PartitionedLS.jl:294-295)"); return PARTLS_ERR_BAD_ARG; }
     partls_status st = ctx_prepare(c, X, N, M, ldX, y, 0, P, K, ldP, eta, /*faithful=*/true, 0);
     if (st != PARTLS_OK) return st;
+    return partls_alt_prepared(c, eps, T, alpha0, beta0, alpha, beta, t, opt, iters);
+}
+
+partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const double *alpha0, const double *beta0,
+                                  double *alpha, double *beta, double *t, double *opt, int64_t *iters)
+{
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_alt_prepared: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (!alpha0 || !beta0 || !alpha || !beta || !t || !opt) { set_error("partls_fit_alt: NULL argument"); return PARTLS_ERR_BAD_ARG; }
+    if (!(eps > 0.0) || T < 1) { set_error("partls_fit_alt: need eps > 0 and T >= 1 (PartitionedLS.jl:294-295)"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    partls_status st = PARTLS_OK;
+    const int64_t M = c->M, K = c->K;
     if (!proper_partition(c)) { set_error("partls_fit_alt: a feature belongs to more than one group (overlapping partitions are not supported on the device path)"); return PARTLS_ERR_UNSUPPORTED; }
     const int Mp = (int)M + 1, Kp = (int)K + 1, Y = (int)M + 1;
     std::vector<double> a(alpha0, alpha0 + Mp), b(beta0, beta0 + Kp), w((size_t)Mp, 0.0), sols, obj2;
@@ -156,9 +166,18 @@ partls_status partls_fit_bnb(partls_ctx *c, const double *X, int64_t N, int64_t 
                              const int64_t *P, int64_t K, int64_t ldP, double eta,
                              double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
 {
-    if (!alpha || !beta || !t || !opt) { set_error("partls_fit_bnb: NULL argument"); return PARTLS_ERR_BAD_ARG; }
     partls_status st = ctx_prepare(c, X, N, M, ldX, y, 0, P, K, ldP, eta, /*faithful=*/true, 0);
     if (st != PARTLS_OK) return st;
+    return partls_bnb_prepared(c, alpha, beta, t, opt, nopen);
+}
+
+partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
+{
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_prepared: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (!alpha || !beta || !t || !opt) { set_error("partls_fit_bnb: NULL argument"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    partls_status st = PARTLS_OK;
+    const int64_t M = c->M, K = c->K;
     if (!proper_partition(c)) { set_error("partls_fit_bnb: a feature belongs to more than one group (overlapping partitions are not supported on the device path)"); return PARTLS_ERR_UNSUPPORTED; }
     const int Mp = (int)M + 1, Kp = (int)K + 1;
     std::vector<int> grp((size_t)Mp);
