@@ -11,6 +11,7 @@
 // Partial tiles go to a per-chunk slab and are summed in a fixed order by gram_reduce (bitwise reproducible;
 // no float atomics).  Roofline: fp64 MFMA bound — 2*N*(M+2)^2/2 flops over 8*N*M bytes (intensity ~ M/8 flop/B).
 #include "common.h"
+#include <cstdlib>
 
 namespace partls {
 
@@ -20,53 +21,80 @@ static constexpr int GT = 64;      // macro tile edge
 static constexpr int GK = 32;      // samples per LDS panel
 static constexpr int GLD = 34;     // padded panel stride (doubles): bank = (4c + 2s) % 64, distinct per 32-lane group
 
-__device__ __forceinline__ double z_value(const double *__restrict__ X, const double *__restrict__ y, int64_t ldX, int M,
-                                          int col, int64_t row, int64_t row_end)
+// Loading one element of Z = [X 1 y] is split in two so that the global loads stay in flight under the MFMAs:
+//   z_load  : unconditional load from a clamped address (issued one panel ahead, result untouched),
+//   z_value : the selects for the virtual columns (ones / y / padding; only the last 64-column tile, EDGE) and the row
+//             tail, applied when the panel is written to LDS.
+template <bool EDGE>
+__device__ __forceinline__ double z_load(const double *__restrict__ X, int64_t ldX, int M, int col, int64_t rr)
 {
-    if (row >= row_end) return 0.0;
-    if (col < M) return X[row + (int64_t)col * ldX];
-    if (col == M) return 1.0;
-    if (col == M + 1) return y[row];
-    return 0.0;
+    const int cc = EDGE ? (col < M ? col : M - 1) : col;
+    return X[rr + (int64_t)cc * ldX];
+}
+template <bool EDGE>
+__device__ __forceinline__ double z_value(double x, double yv, bool rv, int M, int col)
+{
+    double v = x;
+    if constexpr (EDGE) v = col < M ? x : (col == M ? 1.0 : (col == M + 1 ? yv : 0.0));
+    return rv ? v : 0.0;
 }
 
-__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
-                                                   const double *__restrict__ y, double *__restrict__ slab, int ldg,
-                                                   int64_t rows_per_chunk)
+// Work decomposition (XCD-aware): the samples are cut into row chunks of `chunk_rows`.  Workgroups are dealt round-robin
+// over the 8 XCDs, so `blockIdx.x & 7` labels the XCD group; group x, slice s walks the chunks x + 8*(s + S*j), and the np
+// tile-pair workgroups of one (x, s) walk the SAME chunk sequence in step, so panels are re-read from that XCD's L2 by the
+// other tile pairs (speed only — correctness does not depend on placement).  Each workgroup accumulates all its chunks in
+// registers and writes one partial tile to slab (x*S + s).  Inside, the next 32-sample panel is prefetched into registers
+// (16 independent, unconditional global loads) while the MFMAs of the current one run from LDS.
+template <bool EA, bool EB>
+__device__ __forceinline__ void gram_body(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
+                                          const double *__restrict__ y, double *__restrict__ slab, int ldg,
+                                          int chunk_rows, int S, int I, int J, int xg, int sl, double *sA, double *sB)
 {
-    __shared__ double sA[GT * GLD];
-    __shared__ double sB[GT * GLD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nt = ldg / GT;
-    int I = 0, rem = blockIdx.x;
-    while (rem >= nt - I) { rem -= nt - I; ++I; }
-    const int J = I + rem;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-    const int64_t r1 = (r0 + rows_per_chunk < N) ? r0 + rows_per_chunk : N;
-
     double4_t acc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     const int smp = lane & 31, csub = lane >> 5;       // loader: 32 lanes cover one column's 32 contiguous samples
     const int fr = lane & 15, fk = lane >> 4;          // MFMA fragment coordinates
-    const double *pB = (I == J) ? sA : sB;
+    const bool diag = (I == J);
+    const double *pB = diag ? sA : sB;
+    const int kb_per_chunk = chunk_rows / GK;
+    const int64_t nchunks = (N + chunk_rows - 1) / chunk_rows;
+    const int64_t cstride = (int64_t)8 * S;
 
-    for (int64_t k0 = r0; k0 < r1; k0 += GK) {
-        double va[8], vb[8];
+    double va[8], vb[8], vy = 0.0;                     // raw prefetched values (+ y for the edge tile) and the row predicate
+    bool rv = false;
+    auto fetch = [&](int64_t chunk, int kb) {
+        const int64_t r1 = ((chunk + 1) * chunk_rows < N) ? (chunk + 1) * chunk_rows : N;
+        const int64_t row = chunk * chunk_rows + (int64_t)kb * GK + smp;
+        rv = row < r1;
+        const int64_t rr = rv ? row : r1 - 1;
+        if constexpr (EA || EB) vy = y[rr];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = i * 8 + wave * 2 + csub;
-            va[i] = z_value(X, y, ldX, M, I * GT + c, k0 + smp, r1);
-            if (I != J) vb[i] = z_value(X, y, ldX, M, J * GT + c, k0 + smp, r1);
+            va[i] = z_load<EA>(X, ldX, M, I * GT + c, rr);
+            vb[i] = z_load<EB>(X, ldX, M, J * GT + c, rr);                    // diagonal tiles: same lines, L1 hits
         }
+    };
+
+    int64_t chunk = xg + (int64_t)8 * sl;
+    int kb = 0;
+    bool have = chunk < nchunks;
+    if (have) fetch(chunk, 0);
+    while (have) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = i * 8 + wave * 2 + csub;
-            sA[c * GLD + smp] = va[i];
-            if (I != J) sB[c * GLD + smp] = vb[i];
+            sA[c * GLD + smp] = z_value<EA>(va[i], vy, rv, M, I * GT + c);
+            sB[c * GLD + smp] = z_value<EB>(vb[i], vy, rv, M, J * GT + c);
         }
         __syncthreads();
+        // advance and prefetch the next panel (global loads stay in flight under the MFMAs below)
+        if (++kb == kb_per_chunk) { kb = 0; chunk += cstride; }
+        have = chunk < nchunks && (chunk * chunk_rows + (int64_t)kb * GK) < N;
+        if (have) fetch(chunk, kb);
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             const double a = sA[(wave * 16 + fr) * GLD + ks * 4 + fk];
@@ -79,7 +107,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X,
         __syncthreads();
     }
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-    double *out = slab + (size_t)blockIdx.y * (size_t)ldg * (size_t)ldg;
+    double *out = slab + (size_t)(xg * S + sl) * (size_t)ldg * (size_t)ldg;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -88,6 +116,24 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X,
             const int gj = J * GT + jt * 16 + fr;
             out[(size_t)gi * ldg + gj] = acc[jt][reg];
         }
+}
+
+__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
+                                                   const double *__restrict__ y, double *__restrict__ slab, int ldg,
+                                                   int chunk_rows, int S, int np)
+{
+    __shared__ double sA[GT * GLD];
+    __shared__ double sB[GT * GLD];
+    const int nt = ldg / GT;
+    const int xg = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pair = q % np, sl = q / np;
+    int I = 0, rem = pair;
+    while (rem >= nt - I) { rem -= nt - I; ++I; }
+    const int J = I + rem;
+    // only the last 64-column tile holds the virtual ones / y / padding columns (I <= J)
+    if (J != nt - 1) gram_body<false, false>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
+    else if (I != nt - 1) gram_body<false, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
+    else gram_body<true, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
 }
 
 __global__ void gram_reduce_kernel(const double *__restrict__ slab, int chunks, int ldg, double *__restrict__ G)
@@ -102,30 +148,41 @@ __global__ void gram_reduce_kernel(const double *__restrict__ slab, int chunks, 
     G[idx] = s;
 }
 
-size_t gram_slab_doubles(int64_t N, int64_t M, int *chunks_out, int *ldg_out)
+static void gram_plan(int64_t N, int64_t M, int *ldg_out, int *S_out, int *chunk_rows_out, int *np_out)
 {
     const int n_aug = (int)M + 2;
     const int ldg = ((n_aug + GT - 1) / GT) * GT;
     const int nt = ldg / GT, np = nt * (nt + 1) / 2;
-    int64_t chunks = 2048 / np;
-    if (chunks < 1) chunks = 1;
-    int64_t maxc = (N + 255) / 256;                 // at least 256 rows per chunk
-    if (chunks > maxc) chunks = maxc;
-    if (chunks < 1) chunks = 1;
-    while (chunks > 1 && (size_t)chunks * ldg * ldg * 8 > ((size_t)1 << 30)) --chunks;
-    *chunks_out = (int)chunks;
+    // chunk of all columns ~ 1 MiB so that the S concurrent chunks of an XCD group stay L2 resident
+    int64_t cr = ((int64_t)1 << 20) / ((int64_t)n_aug * 8);
+    cr = (cr / GK) * GK;
+    if (cr < GK) cr = GK;
+    if (cr > 4096) cr = 4096;
+    // many more workgroups than resident slots (512) so that the last partial wave of workgroups is a small tail
+    const char *se = getenv("PARTLS_GRAM_S"), *ce = getenv("PARTLS_GRAM_CR");
+    if (ce) { cr = (atoll(ce) / GK) * GK; if (cr < GK) cr = GK; }
+    int S = se ? atoi(se) : (4096 + 8 * np - 1) / (8 * np);
+    if (S < 1) S = 1;
+    const int64_t nchunks = (N + cr - 1) / cr;
+    while (S > 1 && (int64_t)8 * S > nchunks) --S;                 // no more slices than chunks
+    *ldg_out = ldg; *S_out = S; *chunk_rows_out = (int)cr; *np_out = np;
+}
+
+size_t gram_slab_doubles(int64_t N, int64_t M, int *chunks_out, int *ldg_out)
+{
+    int ldg, S, cr, np;
+    gram_plan(N, M, &ldg, &S, &cr, &np);
+    *chunks_out = 8 * S;                                            // number of partial slabs
     *ldg_out = ldg;
-    return (size_t)chunks * ldg * ldg;
+    return (size_t)8 * S * ldg * ldg;
 }
 
 hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, double *slab, int chunks,
                        int ldg, double *G, hipStream_t s)
 {
-    const int nt = ldg / GT, np = nt * (nt + 1) / 2;
-    int64_t rpc = (N + chunks - 1) / chunks;
-    rpc = ((rpc + GK - 1) / GK) * GK;
-    dim3 grid(np, chunks);
-    hipLaunchKernelGGL(gram_kernel, grid, dim3(256), 0, s, X, N, (int)M, ldX, y, slab, ldg, rpc);
+    int ldg2, S, cr, np;
+    gram_plan(N, M, &ldg2, &S, &cr, &np);
+    hipLaunchKernelGGL(gram_kernel, dim3(8 * S * np), dim3(256), 0, s, X, N, (int)M, ldX, y, slab, ldg, cr, S, np);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int tot = ldg * ldg;
