@@ -75,6 +75,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (!y) { set_error("y is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
     c->prepared = false;
+    c->coop_state_valid = false;
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     st = load_partition(c, P, M, K, ldP);
     if (st != PARTLS_OK) return st;
@@ -164,7 +165,7 @@ static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
 
 partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const std::vector<uint64_t> &free_,
                           const std::vector<uint64_t> &zero, std::vector<double> &sols, std::vector<double> &obj2,
-                          unsigned long long *unconv)
+                          unsigned long long *unconv, bool resume)
 {
     const int n = c->n, ld = n + 1;
     const size_t cnt = pat.size();
@@ -181,8 +182,16 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
     PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
-    if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
-    else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
+    const bool coop = !c->use_reg && cnt == 1 && !getenv("PARTLS_NO_COOP");
+    if (coop) {
+        const size_t need = ((size_t)ld * ld + (size_t)n / 8 + 2) * sizeof(double);      // tableau + basis flags
+        if (c->scratch.bytes < need) c->coop_state_valid = false;
+        PARTLS_HIP_CHECK(c->scratch.ensure(need));
+    } else {
+        c->coop_state_valid = false;
+        if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
+        else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
+    }
     PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodePat.p, pat.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeFree.p, free_.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
@@ -199,7 +208,17 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
     p.node_pat = c->nodePat.as<uint64_t>(); p.node_free = c->nodeFree.as<uint64_t>(); p.node_zero = c->nodeZero.as<uint64_t>();
     p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
-    PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
+    if (coop) {
+        // one large problem: many workgroups cooperate on a single global-memory tableau (sweep_coop.hip)
+        p.T0 = c->Tfull.as<double>();
+        p.resume = (resume && c->coop_state_valid) ? 1 : 0;
+        c->coop_state_valid = true;
+        int nwg = (ld + 15) / 16;
+        if (nwg > 64) nwg = 64;
+        PARTLS_HIP_CHECK(launch_sweep_coop(p, nwg, c->stream));
+    } else {
+        PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
+    }
     unsigned long long counters[2] = {0, 0};
     PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->nodeSol.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(obj2.data(), c->nodeObj.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -51,6 +51,7 @@ struct partls_ctx {
     bool use_reg = false;
     double tol = 0.0;
     unsigned long long last_pivots = 0;
+    bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
 };
 
 namespace partls {
@@ -68,7 +69,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
 // solutions in tableau order (0 for nonbasic); obj2: objective^2 from the tableau corner.
 partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const std::vector<uint64_t> &free_,
                           const std::vector<uint64_t> &zero, std::vector<double> &sols, std::vector<double> &obj2,
-                          unsigned long long *unconv);
+                          unsigned long long *unconv, bool resume = false);
 
 // scaled tableau solution -> w over [features, intercept] (length M+1); a free intercept is recovered from the Gram copy
 void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w);

@@ -107,7 +107,7 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         uint64_t pat = 0, zero = 0;
         for (int k = 0; k < Kp; ++k) { if (b[(size_t)k] > 0.0) pat |= 1ULL << k; else if (b[(size_t)k] == 0.0) zero |= 1ULL << k; }
         unsigned long long unconv = 0;
-        st = solve_nodes(c, {pat}, {0}, {zero}, sols, obj2, &unconv);
+        st = solve_nodes(c, {pat}, {0}, {zero}, sols, obj2, &unconv, /*resume=*/i > 1);   // warm start after the first α-step
         if (st != PARTLS_OK) return st;
         unconv_total += unconv;
         std::vector<double> wv;

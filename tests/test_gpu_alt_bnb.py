@@ -101,3 +101,21 @@ def test_overlapping_partition_rejected_for_alt_bnb(partls):
         with pytest.raises(partls.PartlsError) as ei:
             partls.fit(alg, X, y, P, alpha0=np.ones(5), beta0=np.ones(3))
         assert ei.value.status == partls.lowlevel.ERR_UNSUPPORTED
+
+
+def test_alt_and_opt_beyond_register_kernel(partls, oracle):
+    """n = 301 > 272: enumeration on the global-memory kernel, single solves (Alt alpha-steps, winner re-solve) on the
+    cooperative multi-workgroup kernel; both against the dense oracle."""
+    X, y, P, _ = oracle.synth(20260150, 1500, 300, 4)
+    rng = np.random.default_rng(5)
+    a0 = rng.random(301); b0 = (rng.random(5) - 0.5) * 10
+    ref = oracle.fit_alt(X, y, P, a0, b0)
+    m, _, rep = partls.fit(partls.Alt, X, y, P, alpha0=a0, beta0=b0)
+    assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-6)
+    np.testing.assert_allclose(m.β, ref["beta"], atol=1e-6)
+    ro = oracle.fit_opt(X, y, P)
+    mo, _, repo = partls.fit(partls.Opt, X, y, P)
+    assert abs(repo.opt - ro["opt"]) <= 1e-9 * max(1.0, ro["opt"])
+    np.testing.assert_allclose(mo.α, ro["alpha"], atol=1e-7)
+    np.testing.assert_allclose(mo.β, ro["beta"], atol=1e-7)
