@@ -55,16 +55,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal hooks (never used by the driver): PARTLS_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    # PARTLS_DIST_BACKEND=gloo swaps the transport, so the N>1 control flow can be exercised on a one-GPU box
+    share = os.environ.get("PARTLS_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("PARTLS_DIST_BACKEND", "nccl")
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     import partls_amd
     pls = partls_amd.package()
     L = pls.lowlevel
-    ctx = pls.Context(local_rank)
+    ctx = pls.Context(dev_index)
 
     seed, N, D, K = CONFIGS[args.config]
     P, wstar = pls.synth_truth(seed, D, K)
@@ -82,7 +91,7 @@ def main():
         t_gram, t_prep, t_sweep = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP)
         pivots = ctx.pivots()
         # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
-        _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=dev)
+        _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=red_dev)
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         return dict(npat=npat, local=g1 - g0, opt=opt, best_index=bi, unconv=unconv, t_gram=t_gram, t_prep=t_prep,
                     t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), alpha=a, beta=b, t=t, pivots=pivots)
@@ -105,7 +114,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
 
