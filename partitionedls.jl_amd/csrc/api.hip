@@ -266,6 +266,58 @@ partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double
     return PARTLS_OK;
 }
 
+partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps)
+{
+    const int64_t M = c->M, N = c->N;
+    std::vector<int> sup;
+    for (int m = 0; m <= (int)M; ++m)
+        if (w[(size_t)m] != 0.0 || (m == (int)M && free_intercept)) sup.push_back(m);
+    const int p = (int)sup.size();
+    if (p == 0) return PARTLS_OK;
+    // Cholesky of the regularised Gram on the support (host copy); give up quietly if it is not numerically SPD
+    std::vector<double> Lc((size_t)p * p, 0.0);
+    for (int i = 0; i < p; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = h_reg(c, sup[(size_t)i], sup[(size_t)j]);
+            for (int k = 0; k < j; ++k) s -= Lc[(size_t)i * p + k] * Lc[(size_t)j * p + k];
+            if (i == j) { if (!(s > 0.0)) return PARTLS_OK; Lc[(size_t)i * p + i] = std::sqrt(s); }
+            else Lc[(size_t)i * p + j] = s / Lc[(size_t)j * p + j];
+        }
+    PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
+    PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
+    PARTLS_HIP_CHECK(c->gD.ensure((size_t)(M + 1) * sizeof(double)));
+    std::vector<double> g((size_t)M + 1), d((size_t)p);
+    for (int it = 0; it < steps; ++it) {
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PARTLS_HIP_CHECK(launch_residual(c->dX, N, M, c->ldX, nullptr, c->wdev.as<double>(), w[(size_t)M], nullptr, 1024,
+                                         c->yhatD.as<double>(), c->stream));
+        PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, c->yhatD.as<double>(), c->gD.as<double>(), c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(g.data(), c->gD.p, (size_t)(M + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->eta != 0.0) {                                 // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
+            for (int64_t k = 0; k <= c->K; ++k) {
+                double gs = 0.0;
+                for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) gs += w[(size_t)m];
+                for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) g[(size_t)m] -= c->eta * gs;
+            }
+        }
+        for (int i = 0; i < p; ++i) {                        // L z = g_P
+            double s = g[(size_t)sup[(size_t)i]];
+            for (int k = 0; k < i; ++k) s -= Lc[(size_t)i * p + k] * d[(size_t)k];
+            d[(size_t)i] = s / Lc[(size_t)i * p + i];
+        }
+        for (int i = p - 1; i >= 0; --i) {                   // L' delta = z
+            double s = d[(size_t)i];
+            for (int k = i + 1; k < p; ++k) s -= Lc[(size_t)k * p + i] * d[(size_t)k];
+            d[(size_t)i] = s / Lc[(size_t)i * p + i];
+        }
+        double dn = 0.0, wn = 0.0;
+        for (int i = 0; i < p; ++i) { w[(size_t)sup[(size_t)i]] += d[(size_t)i]; dn += d[(size_t)i] * d[(size_t)i]; wn += w[(size_t)sup[(size_t)i]] * w[(size_t)sup[(size_t)i]]; }
+        if (dn <= 1e-30 * wn) break;
+    }
+    return PARTLS_OK;
+}
+
 // cleanupResult (Opt.jl:34-44) from w = f∘α: raw α_m = w_m / f_m, raw β_k = s_k
 static void cleanup_opt(const partls_ctx *c, const std::vector<double> &w, uint64_t pattern, double *alpha, double *beta, double *t)
 {
@@ -337,7 +389,7 @@ void partls_destroy(partls_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
                       &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
-                      &c->flag, &c->nodePat, &c->nodeFree, &c->nodeZero, &c->nodeSol, &c->nodeObj};
+                      &c->flag, &c->yhatD, &c->gD, &c->nodePat, &c->nodeFree, &c->nodeZero, &c->nodeSol, &c->nodeObj};
     for (DevBuf *b : bufs) b->release();
     for (int w = 0; w < PARTLS_T_COUNT; ++w) { (void)hipEventDestroy(c->ev0[w]); (void)hipEventDestroy(c->ev1[w]); }
     (void)hipStreamDestroy(c->stream);
@@ -448,6 +500,8 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     partls_status st = solve_nodes(c, {(uint64_t)pattern & kmask}, {0}, {0}, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
     unscale_solution(c, sols.data(), w);
+    st = refine_solution(c, w, !c->faithful);             // QR-level accuracy of the winner on ill-conditioned data
+    if (st != PARTLS_OK) return st;
     uint64_t full = (uint64_t)pattern & kmask;
     if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
     else full = (uint64_t)pattern;
@@ -473,6 +527,8 @@ partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alp
     partls_status st = solve_nodes(c, {(uint64_t)pattern}, {0}, {0}, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
     unscale_solution(c, sols.data(), w);
+    st = refine_solution(c, w, false);
+    if (st != PARTLS_OK) return st;
     if (optval) { st = data_objective(c, w, optval); if (st != PARTLS_OK) return st; }
     if (raw_alpha)
         for (int64_t m = 0; m <= c->M; ++m) {

@@ -78,6 +78,9 @@ hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64
 // residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
 hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *w, double t,
                            double *partial, int nblocks, double *yhat, hipStream_t s);
+// g[0..M] = Xo' (y - yhat): the gradient pass of the data-space refinement
+hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *g,
+                      hipStream_t s);
 hipError_t launch_synth(uint64_t seed, int64_t N, int64_t D, const double *wstar_dev, double *X, double *y, hipStream_t s);
 hipError_t launch_finite_check(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int *flag, hipStream_t s);
 

@@ -42,7 +42,7 @@ struct partls_ctx {
     // gram
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
-        wdev, partial, flag, nodePat, nodeFree, nodeZero, nodeSol, nodeObj;
+        wdev, partial, flag, yhatD, gD, nodePat, nodeFree, nodeZero, nodeSol, nodeObj;
     std::vector<double> hG, hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
     int n = 0, kbits = 0, T = 0;
@@ -75,6 +75,11 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
 void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w);
 // ||Xo w - yo||_2 from the data (+ the eta rows): Opt.jl:90
 partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt);
+// Iterative refinement of a solution w (over [features, intercept]) on its own support, in data space: residual and
+// X'r on the device, the small SPD solve on the host Gram copy.  Brings a Gram-based solution (error ~ cond^2 eps) to the
+// accuracy of a QR-based one (the reference's NNLS) as long as cond^2 eps < 1.  `free_intercept`: the intercept is part
+// of the support even when w[M] == 0.
+partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps = 2);
 // regularised augmented Gram entry on the host copy
 double h_reg(const partls_ctx *c, int a, int b);
 partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, int64_t ldX, const void *P, int64_t K, int64_t ldP);

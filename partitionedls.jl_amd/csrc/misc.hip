@@ -193,4 +193,40 @@ hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, c
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// g = Xo' (y - yhat) for iterative refinement of one solution in data space (corrected semi-normal equations):
+// one workgroup per column (the last one is the ones column), coalesced along the column, fixed-order block reduction.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xtr_kernel(const double *__restrict__ X, int64_t N, int64_t M, int64_t ldX,
+                                                  const double *__restrict__ y, const double *__restrict__ yhat,
+                                                  double *__restrict__ g)
+{
+    const int64_t m = blockIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 512) {
+        const double x0 = (m < M) ? X[i + m * ldX] : 1.0;
+        a0 = fma(x0, y[i] - yhat[i], a0);
+        const int64_t i2 = i + 256;
+        if (i2 < N) {
+            const double x1 = (m < M) ? X[i2 + m * ldX] : 1.0;
+            a1 = fma(x1, y[i2] - yhat[i2], a1);
+        }
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) g[m] = red[0];
+}
+
+hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *g,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(xtr_kernel, dim3((unsigned)(M + 1)), dim3(256), 0, s, X, N, M, ldX, y, yhat, g);
+    return hipGetLastError();
+}
+
 }  // namespace partls

@@ -237,6 +237,8 @@ partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, do
         }
     }
     if (best_w.empty()) { set_error("partls_fit_bnb: no feasible leaf found"); return PARTLS_ERR_NOT_CONVERGED; }
+    st = refine_solution(c, best_w, false);
+    if (st != PARTLS_OK) return st;
     // BnB.jl:36-39: β_k = Σ_{m∈k} α_m (signed); α_m ← α_m / β_k; t = β[end]
     std::vector<double> bsum((size_t)Kp, 0.0);
     for (int m = 0; m < Mp; ++m) if (grp[(size_t)m] >= 0) bsum[(size_t)grp[(size_t)m]] += best_w[(size_t)m];

@@ -105,3 +105,23 @@ def test_wide_tableau_boundary_sizes(partls, oracle):
         bo, bp, allopt, unconv = ctx.opt_sweep(0, -1, want_all=True)
         assert unconv == 0
         np.testing.assert_allclose(allopt, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("noise,tol", [(1e-3, 1e-9), (1e-4, 1e-7)])
+def test_ill_conditioned_model_parity(partls, oracle, noise, tol):
+    """cond(Xo) ~ 1/noise (6e3 / 8e4): the Gram-based solve alone loses cond^2*eps digits in the model; the data-space
+    refinement of the winner (refine_solution) restores the accuracy of the reference's QR-based NNLS."""
+    rng = np.random.default_rng(42)
+    N, D, K = 2000, 24, 4
+    Z = rng.standard_normal((N, 6))
+    X = Z @ rng.standard_normal((6, D)) + noise * rng.standard_normal((N, D))
+    grp = np.arange(D) % K
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), grp] = 1
+    y = X @ (rng.random(D) * np.array([1., -2, 3, -1])[grp]) + 0.3 + 0.05 * rng.standard_normal(N)
+    ref = oracle.fit_opt(X, y, P)
+    for alg in (partls.Opt, partls.BnB):
+        m, _, rep = partls.fit(alg, X, y, P)
+        assert abs(rep.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+        np.testing.assert_allclose(m.α, ref["alpha"], atol=tol)
+        np.testing.assert_allclose(m.β, ref["beta"], atol=100 * tol)
+        assert abs(m.t - ref["t"]) < tol
