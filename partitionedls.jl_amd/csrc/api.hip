@@ -132,6 +132,20 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
         PARTLS_HIP_CHECK(launch_layout_reg(c->Tfull.as<double>(), c->n, c->T, c->T0reg.as<double>(), c->stream));
     }
     t_end(c, PARTLS_T_PREP);
+    // two-level sweep: the leading groups whose variables (and nobody else's) all sit among the first tableau variables
+    c->low_groups = 0;
+    if (c->use_reg && c->T >= 3) {
+        const int nsv = sweep_two_small_vars();
+        int v = 0;
+        for (; v < c->kbits - 1 && v < 5; ++v) {
+            bool ok = true;
+            for (int i = nsv; i < c->n && ok; ++i) ok = !((c->mask_tab[(size_t)i] >> v) & 1ULL);
+            if (!ok) break;
+        }
+        const char *lg = getenv("PARTLS_LOW_GROUPS");
+        if (lg && atoi(lg) < v) v = atoi(lg) < 0 ? 0 : atoi(lg);
+        c->low_groups = v;
+    }
 
     c->hG.resize((size_t)c->ldg * c->ldg);
     c->hScale.resize((size_t)c->n);
@@ -157,6 +171,12 @@ static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
         p.T0 = c->T0reg.as<double>();
         const char *kv = getenv("PARTLS_KERNEL");          // "reg" = rank-1 register kernel (A/B); default = blocked pivots
         if (kv && strcmp(kv, "reg") == 0) return launch_sweep_reg(p, c->T, grid, c->stream);
+        // two-level sweep (sweep_two.hip) for pattern chains; "blk" = single-level blocked kernel (A/B, and all node solves)
+        // (experimental, opt-in with PARTLS_KERNEL=two until it beats the single-level kernel)
+        if (!p.node_pat && c->low_groups > 0 && kv && strcmp(kv, "two") == 0) {
+            p.low_groups = c->low_groups;
+            return launch_sweep_two(p, c->T, grid, c->stream);
+        }
         return launch_sweep_blk(p, c->T, grid, c->stream);
     }
     p.T0 = c->Tfull.as<double>();
@@ -449,6 +469,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
     p.n_unconverged = c->counters.as<unsigned long long>();
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
+    p.n_small_pivots = c->counters.as<unsigned long long>() + 2;
 
     t_begin(c, PARTLS_T_SWEEP);
     PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
@@ -456,7 +477,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
 
     std::vector<double> bo((size_t)grid);
     std::vector<int64_t> bp((size_t)grid);
-    unsigned long long cnt[2] = {0, 0};
+    unsigned long long cnt[3] = {0, 0, 0};
     PARTLS_HIP_CHECK(hipMemcpyAsync(bo.data(), c->bestObj.p, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(bp.data(), c->bestPat.p, (size_t)grid * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
@@ -467,12 +488,15 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
     c->last_pivots = cnt[1];
+    c->last_small_pivots = cnt[2];
     if (getenv("PARTLS_PRINT_STAMPS")) {                 // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
         double st[16];
         if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[partls stamps] scan: pre %.0f barrier %.0f post %.0f | gather: work %.0f barrier %.0f | panel: work %.0f barrier %.0f | "
-                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu\n",
-                    st[9], st[10], st[0], st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1]);
+                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu || two-level: pre %.0f build %.0f small-solve %.0f verify %.0f "
+                            "low-gather %.0f small pivots %llu\n",
+                    st[9], st[10], st[0], st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1], st[7], st[12], st[13], st[14],
+                    st[15], cnt[2]);
     }
     double bobj = INFINITY;
     int64_t bpat = -1;

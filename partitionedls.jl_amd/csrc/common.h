@@ -39,7 +39,9 @@ struct SweepParams {
     double *best_obj;            // [gridDim.x] per-workgroup minimum objective
     int64_t *best_pat;           // [gridDim.x] its pattern index (lexicographic tie-break on the index)
     unsigned long long *n_unconverged;   // patterns that hit max_rounds
-    unsigned long long *n_pivots;        // total pivots (diagnostics / flop accounting)
+    unsigned long long *n_pivots;        // total pivots on the (n+1)^2 tableau (diagnostics / flop accounting)
+    unsigned long long *n_small_pivots;  // two-level kernel: pivots on the small (41 x 41) tableau
+    int low_groups;              // two-level kernel: groups 0..low_groups-1 are enumerated on the small tableau (0 = off)
     // Node mode (Alt alpha-steps, BnB node bounds): when node_pat != nullptr chain c is ONE subproblem with its own
     // pattern node_pat[c], free groups node_free[c] (no sign constraint: BnB's relaxed groups, BnB.jl:70-79) and zero
     // groups node_zero[c] (multiplier 0, e.g. beta_k == 0 in Alt.jl:80-81).  chain_len must be 1.  Outputs per node:
@@ -59,6 +61,8 @@ struct SweepParams {
 hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);
 hipError_t launch_sweep_reg(const SweepParams &p, int T, int grid, hipStream_t s);
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s);
+hipError_t launch_sweep_two(const SweepParams &p, int T, int grid, hipStream_t s);   // chain mode only (sweep_two.hip)
+int        sweep_two_small_vars();                       // variables 0..this-1 form the preseeded small set
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 272)
 bool       sweep_reg_supported(int n);
 int        sweep_reg_tiles(int n);

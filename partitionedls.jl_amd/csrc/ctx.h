@@ -50,7 +50,8 @@ struct partls_ctx {
     std::vector<uint64_t> mask_tab;
     bool use_reg = false;
     double tol = 0.0;
-    unsigned long long last_pivots = 0;
+    unsigned long long last_pivots = 0, last_small_pivots = 0;
+    int low_groups = 0;                            // groups 0..low_groups-1 live entirely in tile columns 0-1 (two-level sweep)
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
 };
 
