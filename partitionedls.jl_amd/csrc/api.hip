@@ -137,7 +137,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (c->use_reg && c->T >= 3) {
         const int nsv = sweep_two_small_vars();
         int v = 0;
-        for (; v < c->kbits - 1 && v < 5; ++v) {
+        for (; v < c->kbits - 1 && v < 2; ++v) {     // 2^v patterns per block = one per team of the two-level kernel
             bool ok = true;
             for (int i = nsv; i < c->n && ok; ++i) ok = !((c->mask_tab[(size_t)i] >> v) & 1ULL);
             if (!ok) break;
@@ -175,6 +175,8 @@ static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
         // (experimental, opt-in with PARTLS_KERNEL=two until it beats the single-level kernel)
         if (!p.node_pat && c->low_groups > 0 && kv && strcmp(kv, "two") == 0) {
             p.low_groups = c->low_groups;
+            const char *ec = getenv("PARTLS_LOW_ECAP");        // test hook: 0 forces the classical fallback on every discovery
+            p.low_ecap = ec ? atoi(ec) : 8;
             return launch_sweep_two(p, c->T, grid, c->stream);
         }
         return launch_sweep_blk(p, c->T, grid, c->stream);
@@ -490,13 +492,14 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     c->last_pivots = cnt[1];
     c->last_small_pivots = cnt[2];
     if (getenv("PARTLS_PRINT_STAMPS")) {                 // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
-        double st[16];
+        double st[32] = {0};
         if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[partls stamps] scan: pre %.0f barrier %.0f post %.0f | gather: work %.0f barrier %.0f | panel: work %.0f barrier %.0f | "
                             "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu || two-level: pre %.0f build %.0f small-solve %.0f verify %.0f "
                             "low-gather %.0f small pivots %llu\n",
                     st[9], st[10], st[0], st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1], st[7], st[12], st[13], st[14],
                     st[15], cnt[2]);
+        fprintf(stderr, "[partls stamps] lockstep step: choose %.0f publish %.0f barrier %.0f update %.0f | steps %.0f\n", st[16], st[17], st[18], st[19], st[24]);
     }
     double bobj = INFINITY;
     int64_t bpat = -1;

@@ -43,10 +43,13 @@ __device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat) { return 2 
 // Diagnostic build only (-DPARTLS_STAMPS): per-phase cycle shares of workgroup 0 / thread 0, written to p.scratch[0..7]
 // (a buffer no other code of the kernel reads).  Never quote this build's run time (cdna_hip_programming.md §7).
 #ifdef PARTLS_STAMPS
-#define STAMP_DECL unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP_DECL unsigned long long st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
 #define STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _n = __builtin_amdgcn_s_memtime(); \
                        st_acc[ph] += _n - st_t; st_t = _n; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define STAMP_FLUSH do { if (tid == 0 && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 16; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
+#ifndef PARTLS_STAMP_TID
+#define PARTLS_STAMP_TID 0
+#endif
+#define STAMP_FLUSH do { if (tid == PARTLS_STAMP_TID && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 24; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(ph) do { } while (0)

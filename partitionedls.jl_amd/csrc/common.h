@@ -42,6 +42,7 @@ struct SweepParams {
     unsigned long long *n_pivots;        // total pivots on the (n+1)^2 tableau (diagnostics / flop accounting)
     unsigned long long *n_small_pivots;  // two-level kernel: pivots on the small (41 x 41) tableau
     int low_groups;              // two-level kernel: groups 0..low_groups-1 are enumerated on the small tableau (0 = off)
+    int low_ecap;                // two-level kernel: discovered variables allowed per block (<= 8; fewer forces the classical fallback)
     // Node mode (Alt alpha-steps, BnB node bounds): when node_pat != nullptr chain c is ONE subproblem with its own
     // pattern node_pat[c], free groups node_free[c] (no sign constraint: BnB's relaxed groups, BnB.jl:70-79) and zero
     // groups node_zero[c] (multiplier 0, e.g. beta_k == 0 in Alt.jl:80-81).  chain_len must be 1.  Outputs per node:

@@ -3,7 +3,7 @@ usage: python tools/two_stamps.py N D K seed kernel(two|blk)"""
 import os, sys
 N, D, K, seed = (int(x) for x in sys.argv[1:5]); kernel = sys.argv[5]
 os.environ['PARTLS_KERNEL'] = kernel
-os.environ['PARTLS_LIB'] = os.path.join(os.getcwd(), 'partitionedls.jl_amd', 'libpartls_hip_stamps.so')
+os.environ['PARTLS_LIB'] = os.path.join(os.getcwd(), 'partitionedls.jl_amd', os.environ.get('STAMPLIB', 'libpartls_hip_stamps.so'))
 os.environ['PARTLS_PRINT_STAMPS'] = '1'
 os.environ['PARTLS_GRID'] = '256'
 sys.path.insert(0, os.getcwd())
