@@ -117,9 +117,19 @@ __device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int 
 // updates its own row.
 template <int M, int CW>
 __device__ __forceinline__ bool panel_block(double *P, double *Z, double *U, double *Dinv, int myj, bool my_basic,
-                                            double piv_eps, int tid, int prow)
+                                            double piv_eps, int tid, int prow, bool idle_wave)
 {
     bool any_ok = false;                                    // uniform: was any pivot of the block carried out?
+    // A wave whose 64 row positions all lie beyond the rhs row owns no panel row.  Two waves share a SIMD's issue slots, so
+    // such a wave only keeps the barrier count and the uniform result instead of competing with a real wave.
+    if (idle_wave) {
+#pragma unroll
+        for (int s = 0; s < M; ++s) {
+            __syncthreads();
+            any_ok = any_ok || (Dinv[s] != 0.0);
+        }
+        return any_ok;
+    }
     constexpr int US = MB + 64;                             // U row stride; slots MB.. are per-lane dummies (no same-address stores)
     const int dummy = MB + (tid & 63);
     double pv[M];

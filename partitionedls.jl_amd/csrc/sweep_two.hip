@@ -108,6 +108,7 @@ __device__ __forceinline__ void sweep_body2(const SweepParams &p, double *lds)
     bool basic = false, blocked = false;
     const int mypos = (tid & 15) * RS + (tid >> 4);       // panel row position of variable `tid` (tid < 16 T)
     const int rowc = tid / RS, rowrho = tid - rowc * RS;
+    const bool idle_wave = __builtin_amdgcn_readfirstlane((tid & ~63) > RHSPOS ? 1 : 0) != 0;   // no panel row in this wave
 
     const int v = (T >= 3) ? (p.low_groups < 2 ? p.low_groups : 2) : 0;      // 2^v <= NTEAM patterns per block
     const int64_t bl = (int64_t)1 << v;
@@ -331,8 +332,12 @@ __device__ __forceinline__ void sweep_body2(const SweepParams &p, double *lds)
                                     // which turns it into r / |d|
                                     const double rs = colk ? ainv - 1.0 : -r * inv;
                                     const double rz = colk ? 0.0 : raw;
+                                    // row 2c + pr needs multiplier lane 2c + pr: the odd wave shifts the vector down one lane so that both
+                                    // parities read lane 2c with an IMMEDIATE select (an SGPR select costs a reload + hazard stall per row)
+                                    const double rsh = __shfl_down(rs, 1);
+                                    const double rsx = pr ? rsh : rs;
 #pragma unroll
-                                    for (int c = 0; c < 20; ++c) R[c] = fma(readlane_f64(rs, 2 * c + pr), rz, R[c]);
+                                    for (int c = 0; c < 20; ++c) R[c] = fma(readlane_f64(rsx, 2 * c), rz, R[c]);
                                     Rr = fma(readlane_f64(rs, NSMAX), rz, Rr);
                                     Dg = colk ? -inv : fma(rs, r, Dg);          // lanes != k: rs = -r / d
                                     cs = colk ? cs * ainv : cs;                   // the pivot column becomes column / |d|
@@ -474,14 +479,14 @@ __device__ __forceinline__ void sweep_body2(const SweepParams &p, double *lds)
                         // ---- 2. panel elimination -----------------------------------------------------------------------
                         bool blk_ok = false;
                         switch (m) {
-                            case 1: blk_ok = panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            case 2: blk_ok = panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            case 3: blk_ok = panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            case 4: blk_ok = panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            case 5: blk_ok = panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            case 6: blk_ok = panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            case 7: blk_ok = panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
-                            default: blk_ok = panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31)); break;
+                            case 1: blk_ok = panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            case 2: blk_ok = panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            case 3: blk_ok = panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            case 4: blk_ok = panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            case 5: blk_ok = panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            case 6: blk_ok = panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            case 7: blk_ok = panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
+                            default: blk_ok = panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid < NR ? tid : NR + (tid & 31), idle_wave); break;
                         }
                         STAMP(11);
                         __syncthreads();
