@@ -127,3 +127,26 @@ def test_two_level_rank_deficient_and_duplicates(partls):
     o2, p2, a2, u2, _ = _all_patterns(partls, X, y, P, PARTLS_KERNEL="two")
     assert u2 == 0
     np.testing.assert_allclose(a2, a1, rtol=1e-8, atol=1e-10)
+
+
+def test_two_level_full_c3_sweep_same_winner(partls):
+    """BASELINE config 3 (N=100k, D=256, K=20, 2^20 patterns, device-generated data): both kernels find the same pattern and
+    objective; the two-level kernel needs far fewer pivots on the register tableau."""
+    import torch
+    N, D, K, seed = 100000, 256, 20, 20260003
+    P, wstar = partls.synth_truth(seed, D, K)
+    dev = torch.device("cuda:0")
+    dX = torch.empty(N * D, dtype=torch.float64, device=dev)
+    dy = torch.empty(N, dtype=torch.float64, device=dev)
+    res = {}
+    for kern in ("blk", "two"):
+        with _Env(PARTLS_KERNEL=kern):
+            ctx = partls.Context()
+            ctx.synth_device(seed, N, D, wstar, dX.data_ptr(), dy.data_ptr())
+            ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, 0)
+            obj, pat, _, unc = ctx.opt_sweep(0, ctx.num_patterns())
+            res[kern] = (obj, pat, unc, ctx.pivots())
+    assert res["blk"][2] == 0 and res["two"][2] == 0
+    assert res["blk"][1] == res["two"][1]
+    assert abs(res["blk"][0] - res["two"][0]) <= 1e-10 * res["blk"][0]
+    assert res["two"][3] < 0.6 * res["blk"][3]
