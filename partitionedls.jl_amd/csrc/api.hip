@@ -335,7 +335,7 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         }
         double dn = 0.0, wn = 0.0;
         for (int i = 0; i < p; ++i) { w[(size_t)sup[(size_t)i]] += d[(size_t)i]; dn += d[(size_t)i] * d[(size_t)i]; wn += w[(size_t)sup[(size_t)i]] * w[(size_t)sup[(size_t)i]]; }
-        if (dn <= 1e-30 * wn) break;
+        if (dn <= 1e-24 * wn) break;                         // correction at round-off level (1e-12 relative): converged
     }
     return PARTLS_OK;
 }
