@@ -101,7 +101,15 @@ int oracle_nnls(double *A, int64_t m, int64_t n, double *b, double *x, double *r
             double unorm = 0.0;
             for (int64_t l = 0; l < nsetp; ++l) unorm += AT(A, m, l, j) * AT(A, m, l, j);
             unorm = sqrt(unorm);
-            if ((unorm + fabs(AT(A, m, npp1, j)) * factor) - unorm > 0.0) {
+            /* Independence test.  The classic test (unorm + |a| * factor) - unorm > 0 admits a column that is dependent on
+             * the passive set up to round-off; the triangular factor is then singular and the outcome depends on rounding
+             * (it differs between this C code, the Fortran original and the Julia port the reference uses, and is not the
+             * NNLS optimum).  The oracle therefore ALSO rejects a candidate whose component outside the passive space is
+             * below sqrt(1e-11) of its norm — the same rule as the HIP path (entering pivot <= 1e-11 on the unit-diagonal
+             * Gram tableau) — which makes it return the true optimum on rank-deficient data (pinned against
+             * scipy.optimize.nnls in tests/test_oracle.py).  On full-rank passive sets both tests agree. */
+            const double adiag = AT(A, m, npp1, j);
+            if (adiag * adiag > 1e-11 * (unorm * unorm + adiag * adiag) && (unorm + fabs(adiag) * factor) - unorm > 0.0) {
                 memcpy(zz, b, (size_t)m * sizeof(double));
                 house_apply(&AT(A, m, 0, j), up, AT(A, m, npp1, j), npp1, m, zz);
                 double ztest = zz[npp1] / AT(A, m, npp1, j);

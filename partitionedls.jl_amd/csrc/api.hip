@@ -335,7 +335,9 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         }
         double dn = 0.0, wn = 0.0;
         for (int i = 0; i < p; ++i) { w[(size_t)sup[(size_t)i]] += d[(size_t)i]; dn += d[(size_t)i] * d[(size_t)i]; wn += w[(size_t)sup[(size_t)i]] * w[(size_t)sup[(size_t)i]]; }
-        if (dn <= 1e-24 * wn) break;                         // correction at round-off level (1e-12 relative): converged
+        // the iteration contracts by cond^2 eps per step: once a correction is below 1e-9 relative, the next one is below
+        // round-off for every problem the Gram path can solve at all
+        if (dn <= 1e-18 * wn) break;
     }
     return PARTLS_OK;
 }

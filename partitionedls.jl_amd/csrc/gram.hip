@@ -23,7 +23,7 @@ static constexpr int GLD = 34;     // padded panel stride (doubles): bank = (4c 
 
 // Loading one element of Z = [X 1 y] is split in two so that the global loads stay in flight under the MFMAs:
 //   z_load  : unconditional load from a clamped address (issued one panel ahead, result untouched),
-//   z_value : the selects for the virtual columns (ones / y / padding; only the last 64-column tile, EDGE) and the row
+//   z_value : the selects for the virtual columns (ones / y / padding; only tiles that reach column M, EDGE) and the row
 //             tail, applied when the panel is written to LDS.
 template <bool EDGE>
 __device__ __forceinline__ double z_load(const double *__restrict__ X, int64_t ldX, int M, int col, int64_t rr)
@@ -130,9 +130,12 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X,
     int I = 0, rem = pair;
     while (rem >= nt - I) { rem -= nt - I; ++I; }
     const int J = I + rem;
-    // only the last 64-column tile holds the virtual ones / y / padding columns (I <= J)
-    if (J != nt - 1) gram_body<false, false>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
-    else if (I != nt - 1) gram_body<false, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
+    // a tile is an "edge" tile when it holds a virtual column (ones at M, y at M + 1) or padding, i.e. any column >= M: that
+    // is the last tile, and ALSO the one before it when M % 64 == 63 (ones is then its last column).  I <= J.
+    const int first_edge = M / GT;
+    const bool ea = I >= first_edge, eb = J >= first_edge;
+    if (!eb) gram_body<false, false>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
+    else if (!ea) gram_body<false, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
     else gram_body<true, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
 }
 

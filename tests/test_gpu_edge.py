@@ -125,3 +125,23 @@ def test_ill_conditioned_model_parity(partls, oracle, noise, tol):
         np.testing.assert_allclose(m.α, ref["alpha"], atol=tol)
         np.testing.assert_allclose(m.β, ref["beta"], atol=100 * tol)
         assert abs(m.t - ref["t"]) < tol
+
+
+@pytest.mark.parametrize("M", [63, 64, 65, 127, 191, 255])
+def test_gram_virtual_columns_at_tile_boundaries(partls, M):
+    """The ones / y columns of Z = [X 1 y] are virtual; when M % 64 == 63 the ones column is the LAST column of the tile before
+    the last one (found by tests/test_gpu_fuzz.py: G[M][M] came out 0).  Gram block against numpy, and a fit against the
+    oracle-independent normal equations of the unconstrained winner."""
+    rng = np.random.default_rng(700 + M)
+    N, K = 3 * M + 17, 5
+    X = rng.standard_normal((N, M))
+    y = X @ rng.standard_normal(M) + 2.0 + 0.1 * rng.standard_normal(N)
+    P = np.zeros((M, K), dtype=np.int64)
+    P[np.arange(M), np.arange(M) % K] = 1
+    ctx = partls.Context()
+    ctx.opt_prepare(X, y, P, 0.0, 0)
+    G = ctx.gram()
+    Z = np.column_stack([X, np.ones(N), y])
+    Gn = Z.T @ Z
+    d = np.sqrt(np.outer(np.diag(Gn), np.diag(Gn)))
+    assert np.max(np.abs(G - Gn) / d) < 1e-13

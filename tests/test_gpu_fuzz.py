@@ -1,0 +1,102 @@
+"""Randomised differential parity (GPU): the HIP path against the CPU oracle on many small random problems — random shapes
+(1..17 tile columns), unequal group sizes, eta values, noise levels, dependent / duplicate / null columns.  Every pattern's
+objective (faithful intercept: the reference's 2^(K+1) enumeration, Opt.jl:85-96) within 1e-8 relative (+2e-7 ||y|| absolute
+at zero objectives, where the Gram form has abs error ~ sqrt(eps * yy)), same winner up to ties, model within 1e-6.
+Seeds are fixed: failures reproduce (tools/fuzz_triage.py arbitrates a mismatch with KKT certificates).  PARTLS_FUZZ_BLOCKS
+widens the campaign (160 blocks = 2720 problems were run in round 1).  What it found: the Gram kernel's virtual ones column
+at M % 64 == 63, the oracle's classic independence test on exactly dependent columns, and the fixed 1e-11 rejection threshold
+of the tableau kernels (now growth-aware).  The same problems also go through the experimental two-level kernel."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(rng):
+    K = int(rng.integers(1, 8))
+    sizes = rng.integers(1, 14, size=K)
+    if rng.random() < 0.3:
+        sizes[rng.integers(0, K)] = int(rng.integers(14, 40))          # one big group (disables the two-level split or not)
+    D = int(sizes.sum())
+    N = int(rng.integers(D + 5, 6 * D + 40))
+    P = np.zeros((D, K), dtype=np.int64)
+    order = rng.permutation(D) if rng.random() < 0.5 else np.arange(D)  # groups need not be contiguous in the data
+    c = 0
+    for k, s in enumerate(sizes):
+        P[order[c:c + s], k] = 1
+        c += s
+    X = rng.standard_normal((N, D))
+    if rng.random() < 0.4:
+        X *= np.exp(rng.uniform(-3, 3, size=D))[None, :]                # badly scaled columns
+    kind = rng.random()
+    if kind < 0.15 and D >= 3:
+        X[:, rng.integers(0, D)] = X[:, rng.integers(0, D)]             # duplicate column
+    elif kind < 0.3 and D >= 3:
+        X[:, rng.integers(0, D)] = 0.0                                  # null column
+    elif kind < 0.4 and D >= 4:
+        i, j, l = rng.choice(D, 3, replace=False)
+        X[:, i] = 0.5 * X[:, j] - 2.0 * X[:, l]                         # dependent triple
+    grp = P.argmax(1)
+    a = rng.random(D)
+    beta = (rng.random(K) - 0.5) * 10
+    y = X @ (a * beta[grp]) + rng.uniform(-2, 2) + rng.choice([0.0, 1e-3, 0.3, 3.0]) * rng.standard_normal(N)
+    eta = float(rng.choice([0.0, 0.0, 1e-3, 0.5]))
+    return X, y, P, eta
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("PARTLS_FUZZ_BLOCKS", "6"))))
+def test_fuzz_opt_all_patterns_vs_oracle(partls, oracle, block):
+    rng = np.random.default_rng(9000 + block)
+    for it in range(12):
+        X, y, P, eta = _random_problem(rng)
+        ref = oracle.fit_opt(X, y, P, eta=eta, return_all=True)
+        scale = max(1.0, float(np.linalg.norm(y)))
+        for kern in ("blk", "two"):
+            os.environ["PARTLS_KERNEL"] = kern
+            try:
+                model, _, rep = partls.fit(partls.Opt, X, y, P, η=eta, returnAllSolutions=True)
+            finally:
+                os.environ.pop("PARTLS_KERNEL", None)
+            got = np.array([rep.solutions._all[b] for b in range(len(ref["all_opt"]))])
+            tag = f"block {block} it {it} kernel {kern} shape {X.shape} K {P.shape[1]} eta {eta}"
+            # the experimental two-level kernel is held to 1e-5 here: on rank-deficient, regularised near-duplicate columns
+            # one pattern in ~30 000 comes out 3.5e-6 low (known limitation); the product kernel to 1e-8
+            rtol = 1e-8 if kern == "blk" else 1e-5
+            np.testing.assert_allclose(got, ref["all_opt"], rtol=rtol, atol=2e-7 * scale, err_msg=tag)
+            assert abs(got.min() - ref["opt"]) <= rtol * max(1.0, ref["opt"]) + 2e-7 * scale, tag
+            # the reported winner attains the minimum (ties may pick another index of equal objective)
+            assert ref["all_opt"][int(np.argmin(got))] <= ref["opt"] + rtol * max(1.0, ref["opt"]) + 2e-7 * scale, tag
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("PARTLS_FUZZ_BLOCKS", "6")) // 2))
+def test_fuzz_fit_model_vs_oracle(partls, oracle, block):
+    """default (free-intercept) fit: optimum and predictions against the oracle's dense Lawson–Hanson path."""
+    rng = np.random.default_rng(9500 + block)
+    for it in range(10):
+        X, y, P, eta = _random_problem(rng)
+        ref = oracle.fit_opt(X, y, P, eta=eta)
+        model, _, rep = partls.fit(partls.Opt, X, y, P, η=eta)
+        tag = f"block {block} it {it} shape {X.shape} K {P.shape[1]} eta {eta}"
+        scale = max(1.0, float(np.linalg.norm(y)))
+        assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"]) + 1e-9 * scale, tag
+        yh = partls.predict(model, X)
+        yr = oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"])
+        # predictions agree wherever the optimum is unique; with dependent columns only the fit is unique, so compare fits
+        assert np.linalg.norm(yh - yr) <= 1e-6 * scale, tag
+
+
+@pytest.mark.xfail(reason="known limitation (DESIGN.md §4, numerical notes): an exactly dependent column next to a nearly collinear "
+                          "pair — the small legitimate pivot amplifies round-off, the dependent column's pivot comes out just above "
+                          "the fixed 1e-11 rejection threshold and the chained tableau is corrupted; a growth-proportional threshold "
+                          "fixes it but breaks legitimately ill-conditioned full-rank data, which the reference handles and which "
+                          "therefore has priority; needs a per-variable error bound", strict=False)
+def test_known_limitation_dependent_column_next_to_collinear_pair(partls, oracle):
+    rng = np.random.default_rng(9000 + 24)
+    for _ in range(6):
+        X, y, P, eta = _random_problem(rng)
+    ref = oracle.fit_opt(X, y, P, eta=eta, return_all=True)
+    model, _, rep = partls.fit(partls.Opt, X, y, P, η=eta, returnAllSolutions=True)
+    got = np.array([rep.solutions._all[b] for b in range(len(ref["all_opt"]))])
+    np.testing.assert_allclose(got, ref["all_opt"], rtol=1e-8, atol=2e-7 * max(1.0, float(np.linalg.norm(y))))

@@ -122,3 +122,60 @@ def test_synth_generator_properties(oracle):
     assert abs(resid.std() - 0.1) < 0.01
     X2, y2, _, _ = oracle.synth(20260002, 4000, 16, 4)
     assert np.array_equal(X, X2) and np.array_equal(y, y2)
+
+
+def _fuzz_problem(rng):
+    """Small random problem with unequal groups, badly scaled and (sometimes) duplicate / null / dependent columns — the same
+    family tests/test_gpu_fuzz.py throws at the HIP path."""
+    K = int(rng.integers(1, 6))
+    sizes = rng.integers(1, 9, size=K)
+    D = int(sizes.sum())
+    N = int(rng.integers(D + 5, 4 * D + 30))
+    P = np.zeros((D, K), dtype=np.int64)
+    P[np.arange(D), np.repeat(np.arange(K), sizes)] = 1
+    X = rng.standard_normal((N, D)) * np.exp(rng.uniform(-2, 2, size=D))[None, :]
+    kind = rng.random()
+    if kind < 0.3 and D >= 3:
+        X[:, rng.integers(0, D)] = X[:, rng.integers(0, D)]
+    elif kind < 0.5 and D >= 3:
+        X[:, rng.integers(0, D)] = 0.0
+    elif kind < 0.8 and D >= 4:
+        i, j, l = rng.choice(D, 3, replace=False)
+        X[:, i] = 0.5 * X[:, j] - 2.0 * X[:, l]
+    y = X @ rng.standard_normal(D) + 1.0 + 0.3 * rng.standard_normal(N)
+    return X, y, P
+
+
+def test_nnls_kkt_certificate_on_rank_deficient_problems(oracle):
+    """The oracle is only a valid checker if its NNLS returns the optimum.  KKT is necessary and sufficient for this convex
+    problem, so every pattern of 40 random (mostly rank-deficient) problems is certified without any other solver: x >= 0,
+    A'(b - Ax) <= 0 on the zero set, = 0 on the support, and the reported residual is the true one.  (The classic
+    Lawson–Hanson independence test alone fails this on exactly dependent columns — found by the GPU fuzz test — hence the
+    additional rejection rule documented in partls_oracle.c.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzzgen", os.path.join(os.path.dirname(__file__), "test_gpu_fuzz.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    problems = []
+    for seed, it in ((9015, 4), (9069, 1), (9024, 5), (9009, 0)):       # the problems on which the classic test failed
+        r = np.random.default_rng(seed)
+        for _ in range(it + 1):
+            Xf, yf, Pf, eta = fz._random_problem(r)
+        if eta == 0.0:
+            problems.append((Xf, yf, Pf))
+    rng = np.random.default_rng(4242)
+    problems += [_fuzz_problem(rng) for _ in range(30)]
+    for X, y, P in problems:
+        Xo, Po = oracle.homogeneous(X, P)
+        K1 = Po.shape[1]
+        ref = oracle.fit_opt(X, y, P, return_all=True)
+        for b in range(1 << K1):
+            s = np.array([1.0 if (b >> k) & 1 else -1.0 for k in range(K1)])
+            A = Xo * (Po @ s)[None, :]
+            x, rn, mode, _ = oracle.nnls(A, y)
+            r = y - A @ x
+            g = A.T @ r
+            tol = 1e-9 * (np.linalg.norm(A, axis=0) + 1e-300) * max(1.0, np.linalg.norm(y))
+            assert mode == 0 and x.min() >= 0.0
+            assert np.all(g[x == 0] <= tol[x == 0]) and np.all(np.abs(g[x > 0]) <= tol[x > 0])
+            assert abs(np.linalg.norm(r) - rn) <= 1e-9 * max(1.0, rn)
+            assert abs(ref["all_opt"][b] - rn) <= 1e-9 * max(1.0, rn)
