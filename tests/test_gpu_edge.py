@@ -145,3 +145,45 @@ def test_gram_virtual_columns_at_tile_boundaries(partls, M):
     Gn = Z.T @ Z
     d = np.sqrt(np.outer(np.diag(Gn), np.diag(Gn)))
     assert np.max(np.abs(G - Gn) / d) < 1e-13
+
+
+def test_strided_inputs_through_the_c_abi(partls):
+    """ldX > N and ldP > M (sub-matrices of larger Julia arrays): host pointers are compacted by a 2-D copy, device pointers are
+    used in place with their stride by the Gram / residual / X'r kernels.  Results must equal the contiguous call."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(77)
+    N, M, K, padN, padM = 333, 37, 4, 9, 3
+    X = rng.standard_normal((N, M))
+    P = np.zeros((M, K), dtype=np.int64); P[np.arange(M), np.arange(M) % K] = 1
+    y = X @ (rng.random(M) * np.array([1.0, -2.0, 0.5, -1.0])[np.arange(M) % K]) + 0.4 + 0.05 * rng.standard_normal(N)
+    ref_model, _, ref = partls.fit(partls.Opt, X, y, P)
+    Xbig = np.asfortranarray(rng.standard_normal((N + padN, M)))
+    Xbig[:N, :] = X
+    Pbig = np.asfortranarray(np.full((M + padM, K), 7, dtype=np.int64))
+    Pbig[:M, :] = P
+    lib = partls.lowlevel.lib()
+    h = C.c_void_p()
+    assert lib.partls_create(0, C.byref(h)) == 0
+    try:
+        for on_device in (0, 1):
+            if on_device:
+                dX = torch.from_numpy(np.ascontiguousarray(Xbig.T)).to("cuda:0")      # memory image == column-major Xbig
+                dy = torch.from_numpy(y.copy()).to("cuda:0")
+                xp, yp = C.c_void_p(dX.data_ptr()), C.c_void_p(dy.data_ptr())
+            else:
+                xp, yp = C.c_void_p(Xbig.ctypes.data), C.c_void_p(y.ctypes.data)
+            st = lib.partls_opt_prepare(h, xp, N, M, N + padN, yp, on_device, C.c_void_p(Pbig.ctypes.data), K, M + padM,
+                                        C.c_double(0.0), 0)
+            assert st == 0, lib.partls_last_error()
+            bo, bp, nu = C.c_double(), C.c_int64(), C.c_int64()
+            assert lib.partls_opt_sweep(h, 0, -1, C.byref(bo), C.byref(bp), None, C.byref(nu)) == 0
+            a = np.zeros(M); b = np.zeros(K); t = C.c_double(); o = C.c_double(); bi = C.c_int64()
+            assert lib.partls_opt_finish(h, bp.value, a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+                                         C.byref(t), C.byref(o), C.byref(bi)) == 0
+            assert abs(o.value - ref.opt) <= 1e-12 * max(1.0, ref.opt)
+            np.testing.assert_allclose(a, ref_model.α, atol=1e-10)
+            np.testing.assert_allclose(b, ref_model.β, atol=1e-9)
+            assert abs(t.value - ref_model.t) < 1e-10
+    finally:
+        lib.partls_destroy(h)

@@ -100,3 +100,73 @@ def test_known_limitation_dependent_column_next_to_collinear_pair(partls, oracle
     model, _, rep = partls.fit(partls.Opt, X, y, P, η=eta, returnAllSolutions=True)
     got = np.array([rep.solutions._all[b] for b in range(len(ref["all_opt"]))])
     np.testing.assert_allclose(got, ref["all_opt"], rtol=1e-8, atol=2e-7 * max(1.0, float(np.linalg.norm(y))))
+
+
+def _wellposed_problem(rng, dmax=40):
+    """full-rank random problem (no planted dependencies) with unequal groups and odd N — for the paths whose iterates, not
+    only whose optimum, are compared"""
+    K = int(rng.integers(1, 7))
+    sizes = rng.integers(1, max(2, dmax // K), size=K)
+    D = int(sizes.sum())
+    N = int(rng.integers(D + 7, 5 * D + 61))
+    P = np.zeros((D, K), dtype=np.int64)
+    P[rng.permutation(D), np.repeat(np.arange(K), sizes)] = 1
+    X = rng.standard_normal((N, D)) * np.exp(rng.uniform(-1.5, 1.5, size=D))[None, :]
+    grp = P.argmax(1)
+    y = X @ (rng.random(D) * ((rng.random(K) - 0.5) * 6)[grp]) + rng.uniform(-1, 1) + 0.2 * rng.standard_normal(N)
+    return X, y, P
+
+
+@pytest.mark.parametrize("block", range(max(3, int(os.environ.get("PARTLS_FUZZ_BLOCKS", "6")) // 2)))
+def test_fuzz_bnb_equals_opt_and_oracle(partls, oracle, block):
+    """BnB.jl:30-132 returns the optimum of the same problem as Opt (with the signed intercept of BnB.jl:36-39)."""
+    rng = np.random.default_rng(9700 + block)
+    for it in range(8):
+        X, y, P = _wellposed_problem(rng)
+        eta = float(rng.choice([0.0, 0.1]))
+        ref = oracle.fit_bnb(X, y, P, eta=eta)
+        m1, _, r1 = partls.fit(partls.BnB, X, y, P, η=eta)
+        m2, _, r2 = partls.fit(partls.Opt, X, y, P, η=eta)
+        tag = f"block {block} it {it} shape {X.shape} K {P.shape[1]} eta {eta}"
+        assert abs(r1.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"]), tag
+        assert abs(r1.opt - r2.opt) <= 1e-8 * max(1.0, r2.opt), tag
+        np.testing.assert_allclose(partls.predict(m1, X), oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"]),
+                                   atol=1e-6 * max(1.0, float(np.linalg.norm(y))), err_msg=tag)
+
+
+@pytest.mark.parametrize("block", range(max(3, int(os.environ.get("PARTLS_FUZZ_BLOCKS", "6")) // 2)))
+def test_fuzz_alt_same_start_vs_oracle(partls, oracle, block):
+    """Alt.jl:50-124 from the same (alpha0, beta0): the alternating NNLS / least-squares iterates are deterministic, so the
+    final objective and model agree with the oracle's."""
+    rng = np.random.default_rng(9800 + block)
+    for it in range(8):
+        X, y, P = _wellposed_problem(rng, dmax=30)
+        M, K = P.shape
+        a0 = rng.random(M + 1)
+        b0 = (rng.random(K + 1) - 0.5) * 10
+        T = int(rng.integers(1, 12))
+        ref = oracle.fit_alt(X, y, P, a0, b0, eta=0.0, eps=1e-9, T=T)
+        m, _, rep = partls.fit(partls.Alt, X, y, P, η=0.0, ϵ=1e-9, T=T, alpha0=a0, beta0=b0)
+        tag = f"block {block} it {it} shape {X.shape} K {K} T {T}"
+        assert abs(rep.opt - ref["opt"]) <= 1e-7 * max(1.0, ref["opt"]), tag
+        np.testing.assert_allclose(partls.predict(m, X), oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"]),
+                                   atol=1e-6 * max(1.0, float(np.linalg.norm(y))), err_msg=tag)
+
+
+@pytest.mark.parametrize("D", [273, 300, 340])
+def test_fuzz_large_n_generic_path_vs_oracle(partls, oracle, D):
+    """n > 272 variables: the global-memory tableau kernels (sweep_generic.hip chains, sweep_coop.hip single nodes)."""
+    rng = np.random.default_rng(9900 + D)
+    K = 3
+    N = 2 * D + 11
+    P = np.zeros((D, K), dtype=np.int64)
+    P[np.arange(D), rng.integers(0, K, size=D)] = 1
+    X = rng.standard_normal((N, D))
+    grp = P.argmax(1)
+    y = X @ (rng.random(D) * np.array([2.0, -1.0, 0.5])[grp]) + 0.7 + 0.1 * rng.standard_normal(N)
+    ref = oracle.fit_opt(X, y, P, return_all=True)
+    model, _, rep = partls.fit(partls.Opt, X, y, P, returnAllSolutions=True)
+    got = np.array([rep.solutions._all[b] for b in range(len(ref["all_opt"]))])
+    np.testing.assert_allclose(got, ref["all_opt"], rtol=1e-8, atol=1e-8)
+    m2, _, r2 = partls.fit(partls.Opt, X, y, P)
+    assert abs(r2.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
