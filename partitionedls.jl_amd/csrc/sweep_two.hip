@@ -1,26 +1,30 @@
-// sweep_two.hip — two-level sign-pattern sweep: the blocked register-tableau kernel of sweep_blk.hip walks only the HIGH
-// groups; the LOW groups (those whose variables all lie in tile columns 0-1) are enumerated on a small LDS tableau.
+// sweep_two.hip — EXPERIMENTAL two-level sign-pattern sweep (opt-in: PARTLS_KERNEL=two; the product default is sweep_blk.hip).
+// The blocked register-tableau machinery of sweep_blk.hip walks only the HIGH groups; the LOW groups (at most two: those whose
+// variables all lie in tile columns 0-1) are enumerated on small register-resident tableaus.
 //
 // Replaces the loop body of fit(Opt), Opt.jl:87-90, like sweep_blk.hip (same subproblems, same KKT conditions, same
 // tolerances), but changes which tableau pays for a sign flip.  In Gray order the lowest groups flip most often, and in
 // sweep_blk.hip every flip costs ~|P_k| exchanges on the (n+1)^2 register tableau.  Here, for a block of 2^v consecutive
-// Gray indices (v = p.low_groups; the HIGH part of the pattern is constant inside a block):
+// Gray indices (v = p.low_groups <= 2; the HIGH part of the pattern is constant inside a block):
 //   1. frozen big solve : the register tableau is brought to the optimum of the HIGH configuration with every LOW
 //      variable held nonbasic (sign code 0) — ordinary blocked pivots, once per 2^v patterns;
 //   2. low panel        : tile columns 0 and 1 of that tableau (the LOW variables' columns, all rows) are gathered into a
 //      persistent LDS panel LP[slot][row position];
-//   3. small solves     : for each of the 2^v LOW sign choices the subproblem restricted to the small set
-//      (slots = variables 0..31 + discovered ones) is a principal-pivoting problem on the 41 x 41 tableau W whose
-//      entries are read from LP (rows of the small set): the Schur complement of the big basis.  Pivots on W cost
-//      41^2 FMAs instead of (n+1)^2;
-//   4. verification     : the frozen variables' rhs under the small solution is q_r - sum_j LP[j][r] * (+-u_j) over the
+//   3. small solves     : for each of the 2^v LOW sign choices the subproblem restricted to the small set (slots = variables
+//      0..31 + discovered ones) is a principal-pivoting problem on a 41 x 41 tableau whose entries are read from LP (rows of
+//      the small set): the Schur complement of the big basis.  The 2^v tableaus are solved CONCURRENTLY, one per team of two
+//      waves (lane = column, rows interleaved over the two waves in registers), all teams in lockstep with one LDS barrier
+//      per pivot; a pivot there costs 41^2 FMAs instead of (n+1)^2;
+//   4. verification     : the frozen variables' rhs under a small solution is q_r - sum_j LP[j][r] * (+-u_j) over the
 //      small variables j whose status changed (u = small rhs, + entered / - left): an exact KKT check of the FULL
 //      subproblem.  A frozen violator is "discovered": its column is gathered from the registers (the shared gather code
-//      of the block loop) and appended to LP, and the small solve restarts with it.  If more than ECAP variables are
-//      discovered in a block, the rest of the block is solved the classical way on the register tableau (the low
-//      variables are simply unfrozen), so the result never depends on the heuristic split.
-// The objective of a pattern is the corner of W (or of the register tableau in the classical fallback).
+//      of the block loop, which then runs with a zero pivot count) and appended to LP, and the affected patterns are solved
+//      again.  If more than ECAP variables are discovered in a block, its pending patterns are solved the classical way on
+//      the register tableau (the low variables are simply unfrozen), so the result never depends on the heuristic split.
+// The objective of a pattern is the corner of its small tableau (or of the register tableau in the classical fallback).
 // Chain mode only (node mode stays on sweep_blk.hip).  v = 0 degenerates to the algorithm of sweep_blk.hip.
+// Status: bit-compatible with sweep_blk.hip on all tests, 2.9x fewer big-tableau pivots, but 121.9 ms vs 97.6 ms
+// on C3 — an unblocked small pivot is a ~1 k-cycle latency chain; variants and measurements in tools/experiments/.
 #include "blk_common.h"
 
 namespace partls {
@@ -31,7 +35,6 @@ using namespace blk;
 static constexpr int TLV = 32;                 // small-set slots taken by tile columns 0 and 1
 static constexpr int ECAP = 8;                 // discovered variables per block
 static constexpr int NSMAX = TLV + ECAP;       // small variables; the rhs has index NSMAX
-static constexpr int SW = NSMAX + 1;           // small tableau edge (odd)
 
 constexpr int nrows(int T) { return 16 * rstride(T) + 1; }          // panel row positions incl. the rhs row (odd)
 constexpr int cw2(int T) { return nrows(T) + 32; }                  // block panel column: + 32 dummy slots (odd)
