@@ -210,9 +210,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                     tiles &= tiles - 1;
                 }
             }
-            const double obj = sqrt(corner > 0.0 ? corner : 0.0);
-            if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
-            if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
+            // patterns are ranked on objective^2 (the tableau corner; sqrt is monotone): one sqrt per workgroup instead of one per
+            // pattern, unless every pattern's objective is wanted
+            const double obj2 = corner > 0.0 ? corner : 0.0;
+            if (p.all_opt && tid == 0) p.all_opt[pat] = sqrt(obj2);
+            if (obj2 < best_obj || (obj2 == best_obj && (long long)pat < best_pat)) { best_obj = obj2; best_pat = (long long)pat; }
         }
         if (p.node_sol) {
             if (has_var) p.node_sol[(size_t)chain * p.node_ld + tid] = basic ? q : 0.0;
@@ -221,7 +223,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
     }
     STAMP_FLUSH;
     if (tid == 0) {
-        p.best_obj[blockIdx.x] = best_obj;
+        p.best_obj[blockIdx.x] = sqrt(best_obj);
         p.best_pat[blockIdx.x] = best_pat;
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
