@@ -10,6 +10,9 @@
 //     tableau problem with the not-yet-branched groups FREE.  Nodes are bounded in batches (best-first frontier), the
 //     incumbent prunes (BnB.jl:102); the node count depends on the search order and is not a parity quantity.
 #include "ctx.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <queue>
@@ -107,7 +110,9 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         uint64_t pat = 0, zero = 0;
         for (int k = 0; k < Kp; ++k) { if (b[(size_t)k] > 0.0) pat |= 1ULL << k; else if (b[(size_t)k] == 0.0) zero |= 1ULL << k; }
         unsigned long long unconv = 0;
+        const auto tt0 = std::chrono::steady_clock::now();
         st = solve_nodes(c, {pat}, {0}, {zero}, sols, obj2, &unconv, /*resume=*/i > 1);   // warm start after the first α-step
+        const auto tt1 = std::chrono::steady_clock::now();
         if (st != PARTLS_OK) return st;
         unconv_total += unconv;
         std::vector<double> wv;
@@ -147,6 +152,7 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         const double o2 = gram_objective2(c, w);
         oldopt = optval;
         optval = std::sqrt(o2 > 0.0 ? o2 : 0.0);
+        if (getenv("PARTLS_ALT_TRACE")) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms, rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
         ++i;
     }
     w_from();

@@ -1,12 +1,20 @@
-// sweep_coop.hip — ONE large subproblem solved by many workgroups (cooperative launch, grid-wide barriers).
+// sweep_coop.hip — ONE large subproblem solved by many workgroups (cooperative launch, grid-wide barriers), BLOCKED pivots.
 //
 // Used for single "node" solves whose tableau does not fit the register-resident kernel (n > 272): the α-step of
 // fit(Alt) at BASELINE config 4 (n = 513, Alt.jl:80-90) and the winner re-solve of fit(Opt) at such sizes.  Same
 // algorithm and decisions as sweep_generic.hip; the (n+1)^2 tableau lives in global memory (2.1 MB at n = 513,
 // L2 resident) and every workgroup owns a slice of its ROWS.  All control state (basis flags, rejections, the violator
-// masks) is replicated per workgroup and evolves identically everywhere because every workgroup reads the same
-// pivot row / rhs row after each grid barrier — no cross-workgroup messages besides the tableau itself.
-// Per pivot: copy row k (= column k by symmetry) to LDS -> grid.sync() -> rank-1 update of the owned rows -> grid.sync().
+// list) is replicated per workgroup and evolves identically everywhere because every workgroup reads the same data after
+// each grid barrier — no cross-workgroup messages besides the tableau itself.
+//
+// The violators of one KKT scan are exchanged in blocks of up to mb <= 16 pivots (as in sweep_blk.hip):
+//   1. panel   : every workgroup copies the block's pivot rows (= columns, by symmetry) from global memory to LDS, P[mb][ld];
+//   2. factor  : every workgroup eliminates the panel REDUNDANTLY — mb sequential Gauss–Jordan steps with block-local
+//                barriers only; column s as of its own step is kept in Z[s][.], 1/d_s in dinv[s] (0 = rejected as dependent);
+//   3. update  : each workgroup applies the fused rank-m update T_ic -= sum_s Z_s[i] Z_s[c] / d_s to ITS rows, then overwrites
+//                the rows / columns of the pivoted variables from the final panel;
+//   4. one grid barrier.
+// So the grid synchronises once per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables).
 #include "common.h"
 #include <hip/hip_cooperative_groups.h>
 
@@ -16,19 +24,25 @@ namespace partls {
 
 static constexpr int COOP_THREADS = 256;
 static constexpr int COOP_MAXWORDS = 16;
+static constexpr int COOP_MB = 16;
 
 __device__ __forceinline__ int coop_sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
 
-__global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p)
+__global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p, int mb)
 {
     cg::grid_group grid = cg::this_grid();
     const int n = p.n, ld = n + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ double smem[];
-    double *r = smem;                                             // pivot row, ld doubles
-    uint8_t *s_basic = reinterpret_cast<uint8_t *>(smem + ld);
+    double *Pn = smem;                                            // [mb][ld] panel: the block's pivot columns, all rows
+    double *Zn = Pn + (size_t)mb * ld;                            // [mb][ld] column s as of its own step
+    double *dinv = Zn + (size_t)mb * ld;                          // [COOP_MB] 1/d_s (0: rejected)
+    double *uj = dinv + COOP_MB;                                  // [COOP_MB] pivot-row entries of the current step
+    uint8_t *s_basic = reinterpret_cast<uint8_t *>(uj + COOP_MB);
     uint8_t *s_blocked = s_basic + n;
     __shared__ unsigned long long s_inf[COOP_MAXWORDS];
+    __shared__ int s_viol[COOP_MAXWORDS * 64];
+    __shared__ int s_nv;
 
     double *T = p.scratch;
     const int nwg = gridDim.x, wg = blockIdx.x;
@@ -78,57 +92,84 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p)
         bool all;
         if (count < ninf_best) { ninf_best = count; patience = 3; all = true; }
         else if (patience > 0) { --patience; all = true; }
-        else all = false;
+        else all = false;                                         // backup rule: only the largest violator
         if (++rounds > p.max_rounds) { ++nunconv; break; }
-
-        int w = all ? 0 : nwords - 1;
-        unsigned long long bits = s_inf[w];
-        for (;;) {
-            int k;
-            if (all) {
-                while (bits == 0 && w + 1 < nwords) { ++w; bits = s_inf[w]; }
-                if (bits == 0) break;
-                k = (w << 6) + __builtin_ctzll(bits);
-                bits &= bits - 1;
-            } else {
-                while (bits == 0 && w > 0) { --w; bits = s_inf[w]; }
-                if (bits == 0) break;
-                k = (w << 6) + 63 - __builtin_clzll(bits);
-                bits = 0; w = 0;
+        // the violator list of this round (ascending; the backup rule keeps only the last one)
+        if (tid == 0) {
+            int nv = 0;
+            for (int w = 0; w < nwords; ++w) {
+                unsigned long long bits = s_inf[w];
+                while (bits) { s_viol[nv++] = (w << 6) + __builtin_ctzll(bits); bits &= bits - 1; }
             }
-            // ---- pivot k -------------------------------------------------------------------------------------------------
-            for (int i = tid; i < ld; i += COOP_THREADS) r[i] = __builtin_nontemporal_load(&T[(size_t)k * ld + i]);
-            __syncthreads();
-            grid.sync();                                   // everybody holds row k before its owner rewrites it
-            __threadfence();
-            const double d = r[k];
-            if (!s_basic[k] && !(d > p.piv_eps)) {         // dependent column: rejected for the current basis
-                __syncthreads();
-                if (tid == 0) s_blocked[k] = 1;
-                __syncthreads();
-                if (!all) break;
-                continue;
-            }
-            const double inv = 1.0 / d, ainv = 1.0 / fabs(d);
-            for (int i = row0 + wave; i < row1; i += COOP_THREADS / 64) {
-                const double ri = r[i], mi = -ri * inv;
-                double *row = T + (size_t)i * ld;
-                if (i == k) {
-                    for (int j = lane; j < ld; j += 64) row[j] = (j == k) ? -inv : r[j] * ainv;
-                } else {
-                    for (int j = lane; j < ld; j += 64) row[j] = (j == k) ? ri * ainv : fma(mi, r[j], row[j]);
-                }
-            }
-            __syncthreads();
-            if (tid == 0) s_basic[k] ^= 1;
-            __threadfence();
-            grid.sync();                                   // the whole tableau is updated before the next row is read
-            __threadfence();                               // agent-scope acquire on this CU (per-XCD L2s are not coherent)
-            progress = true;
-            ++npiv;
-            if (!all) break;
+            if (!all) { s_viol[0] = s_viol[nv - 1]; nv = 1; }
+            s_nv = nv;
         }
         __syncthreads();
+        const int nv = s_nv;
+
+        for (int b0 = 0; b0 < nv; b0 += mb) {
+            const int m = (nv - b0 < mb) ? nv - b0 : mb;
+            const int *ks = s_viol + b0;
+            // ---- 1. panel: rows ks[j] of the tableau (= columns, by symmetry) ----------------------------------------------
+            for (int j = 0; j < m; ++j) {
+                const double *src = T + (size_t)ks[j] * ld;
+                for (int i = tid; i < ld; i += COOP_THREADS) Pn[(size_t)j * ld + i] = __builtin_nontemporal_load(&src[i]);
+            }
+            __syncthreads();
+            // ---- 2. redundant elimination of the panel (block-local barriers only) ---------------------------------------
+            for (int s = 0; s < m; ++s) {
+                const int k = ks[s];
+                if (tid < m) uj[tid] = Pn[(size_t)tid * ld + k];                 // pivot-row entries before the step
+                __syncthreads();
+                const double d = uj[s];
+                const bool ok = s_basic[k] || (d > p.piv_eps);                   // dependent column: rejected for the current basis
+                const double inv = ok ? 1.0 / d : 0.0, ainv = fabs(inv);
+                if (ok) {
+                    for (int i = tid; i < ld; i += COOP_THREADS) {
+                        const double zi = Pn[(size_t)s * ld + i];
+                        Zn[(size_t)s * ld + i] = zi;
+                        const double mi = -zi * inv;
+                        for (int j = 0; j < m; ++j) {
+                            if (j == s) continue;
+                            const double pji = Pn[(size_t)j * ld + i];
+                            Pn[(size_t)j * ld + i] = (i == k) ? uj[j] * ainv : fma(mi, uj[j], pji);
+                        }
+                        Pn[(size_t)s * ld + i] = (i == k) ? -inv : zi * ainv;
+                    }
+                }
+                if (tid == 0) dinv[s] = inv;
+                __syncthreads();
+            }
+            // ---- 3. fused rank-m update of the owned rows, then the pivoted rows / columns from the final panel ------------
+            for (int i = row0 + wave; i < row1; i += COOP_THREADS / 64) {
+                double *row = T + (size_t)i * ld;
+                for (int c = lane; c < ld; c += 64) {
+                    double acc = row[c];
+                    for (int s = 0; s < m; ++s) {
+                        const double f = dinv[s];
+                        if (f != 0.0) acc = fma(-Zn[(size_t)s * ld + i] * f, Zn[(size_t)s * ld + c], acc);
+                    }
+                    row[c] = acc;
+                }
+            }
+            __syncthreads();                                                       // all generic updates of this workgroup are issued
+            for (int j = 0; j < m; ++j) {
+                const int k = ks[j];
+                for (int i = row0 + tid; i < row1; i += COOP_THREADS) T[(size_t)i * ld + k] = Pn[(size_t)j * ld + i];   // column k
+                if (k >= row0 && k < row1)
+                    for (int c = tid; c < ld; c += COOP_THREADS) T[(size_t)k * ld + c] = Pn[(size_t)j * ld + c];       // row k
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int j = 0; j < m; ++j) {
+                    if (dinv[j] != 0.0) s_basic[ks[j]] ^= 1; else s_blocked[ks[j]] = 1;
+                }
+            }
+            for (int j = 0; j < m; ++j) if (dinv[j] != 0.0) { progress = true; ++npiv; }
+            __threadfence();
+            grid.sync();                                   // the whole tableau is updated before anybody reads it again
+            __threadfence();                               // agent-scope acquire on this CU (per-XCD L2s are not coherent)
+        }
     }
     if (wg == 0) {
         for (int i = tid; i < n; i += COOP_THREADS) flagbuf[i] = s_basic[i];
@@ -145,9 +186,17 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p)
 
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s)
 {
-    const size_t shmem = (size_t)(p.n + 1) * sizeof(double) + 2 * (size_t)p.n + 16;
+    const int ld = p.n + 1;
+    // pivots per block: two [mb][ld] LDS images within ~136 KB
+    int mb = (int)((size_t)136 * 1024 / ((size_t)2 * ld * sizeof(double)));
+    if (mb > COOP_MB) mb = COOP_MB;
+    if (mb < 1) mb = 1;
+    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + 2 * COOP_MB * sizeof(double) + 2 * (size_t)p.n + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_coop_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
     SweepParams pc = p;
-    void *args[] = {&pc};
+    void *args[] = {&pc, &mb};
     return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&sweep_coop_kernel), dim3(nwg), dim3(COOP_THREADS), args,
                                       (unsigned)shmem, s);
 }
