@@ -43,7 +43,12 @@ double gram_objective2(const partls_ctx *c, const std::vector<double> &w)
     for (int i = 0; i < Mp; ++i) {
         if (w[(size_t)i] == 0.0) continue;
         double gi = 0.0;
-        for (int j = 0; j < Mp; ++j) gi += h_reg(c, i, j) * w[(size_t)j];
+        if (c->eta == 0.0) {
+            const double *Grow = &c->hG[(size_t)i * c->ldg];
+            for (int j = 0; j < Mp; ++j) gi += Grow[j] * w[(size_t)j];
+        } else {
+            for (int j = 0; j < Mp; ++j) gi += h_reg(c, i, j) * w[(size_t)j];
+        }
         s += w[(size_t)i] * (gi - 2.0 * h_reg(c, i, Y));
     }
     return s;
@@ -137,10 +142,20 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
             const int gm = grp[(size_t)m];
             if (gm < 0 || a[(size_t)m] == 0.0) continue;
             g[(size_t)gm] += a[(size_t)m] * h_reg(c, m, Y);
-            for (int m2 = 0; m2 < Mp; ++m2) {
-                const int g2 = grp[(size_t)m2];
-                if (g2 < 0 || a[(size_t)m2] == 0.0) continue;
-                H[(size_t)gm * Kp + g2] += a[(size_t)m] * h_reg(c, m, m2) * a[(size_t)m2];
+            if (c->eta == 0.0) {                                   // plain Gram row: no per-entry call (M^2 entries per iteration)
+                const double *Grow = &c->hG[(size_t)m * c->ldg];
+                double *Hrow = &H[(size_t)gm * Kp];
+                const double am = a[(size_t)m];
+                for (int m2 = 0; m2 < Mp; ++m2) {
+                    const int g2 = grp[(size_t)m2];
+                    if (g2 >= 0) Hrow[g2] += am * Grow[m2] * a[(size_t)m2];
+                }
+            } else {
+                for (int m2 = 0; m2 < Mp; ++m2) {
+                    const int g2 = grp[(size_t)m2];
+                    if (g2 < 0 || a[(size_t)m2] == 0.0) continue;
+                    H[(size_t)gm * Kp + g2] += a[(size_t)m] * h_reg(c, m, m2) * a[(size_t)m2];
+                }
             }
         }
         // groups without members (possible only for user groups with no feature) get a unit diagonal so H stays regular
