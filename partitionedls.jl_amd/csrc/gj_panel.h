@@ -1,0 +1,97 @@
+// gj_panel.h — block principal pivots on a global-memory tableau (shared by sweep_generic.hip and sweep_coop.hip).
+//
+// A block is a list ks[0..m) of pivot variables.  The panel P[j][i] = T[i][ks[j]] (all rows i; read as row ks[j] by symmetry)
+// is eliminated in LDS by m sequential Gauss–Jordan steps in the unified convention of the project
+//        T_ij -= T_ik T_kj / d ,  T_ik = T_ik / |d| ,  T_kk = -1/d        (d = T_kk; the same formula enters and removes),
+// keeping column s as of its own step in Z[s][.] and 1/d_s in dinv[s] (0: the entering column was rejected as dependent on the
+// current basis, Lawson–Hanson).  The caller then applies  T_ic -= sum_s Z_s[i] Z_s[c] / d_s  to its rows in ONE pass and
+// overwrites the rows / columns of the pivoted variables from the final panel.  Block-local barriers only.
+#pragma once
+#include "common.h"
+
+namespace partls {
+
+static constexpr int GJ_MB = 16;              // pivots per block at most
+
+template <int NT>
+__device__ __forceinline__ void gj_panel_load(const double *T, int ld, const int *ks, int m, double *Pn, int tid)
+{
+    for (int j = 0; j < m; ++j) {
+        const double *src = T + (size_t)ks[j] * ld;
+        for (int i = tid; i < ld; i += NT) Pn[(size_t)j * ld + i] = __builtin_nontemporal_load(&src[i]);
+    }
+    __syncthreads();
+}
+
+// returns the number of accepted pivots (uniform)
+template <int NT>
+__device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double *dinv, double *uj, const int *ks, int m, int ld,
+                                                  const uint8_t *s_basic, double piv_eps, int tid)
+{
+    int accepted = 0;
+    for (int s = 0; s < m; ++s) {
+        const int k = ks[s];
+        if (tid < m) uj[tid] = Pn[(size_t)tid * ld + k];                 // pivot-row entries before the step
+        __syncthreads();
+        const double d = uj[s];
+        const bool ok = s_basic[k] || (d > piv_eps);                     // dependent column: rejected for the current basis
+        const double inv = ok ? 1.0 / d : 0.0, ainv = fabs(inv);
+        if (ok) {
+            ++accepted;
+            for (int i = tid; i < ld; i += NT) {
+                const double zi = Pn[(size_t)s * ld + i];
+                Zn[(size_t)s * ld + i] = zi;
+                const double mi = -zi * inv;
+                for (int j = 0; j < m; ++j) {
+                    if (j == s) continue;
+                    const double pji = Pn[(size_t)j * ld + i];
+                    Pn[(size_t)j * ld + i] = (i == k) ? uj[j] * ainv : fma(mi, uj[j], pji);
+                }
+                Pn[(size_t)s * ld + i] = (i == k) ? -inv : zi * ainv;
+            }
+        }
+        if (tid == 0) dinv[s] = inv;
+        __syncthreads();
+    }
+    return accepted;
+}
+
+// fused rank-m update of rows [row0, row1) (one wave per row), then the pivoted rows / columns from the final panel
+template <int NT>
+__device__ __forceinline__ void gj_apply(double *T, int ld, int row0, int row1, const double *Pn, const double *Zn, const double *dinv,
+                                         const int *ks, int m, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = row0 + wave; i < row1; i += NT / 64) {
+        double *row = T + (size_t)i * ld;
+        double fi[GJ_MB];
+#pragma unroll
+        for (int s = 0; s < GJ_MB; ++s) fi[s] = (s < m) ? -Zn[(size_t)s * ld + i] * dinv[s] : 0.0;     // 0 for rejected pivots
+        for (int c = lane; c < ld; c += 64) {
+            double acc = row[c];
+#pragma unroll
+            for (int s = 0; s < GJ_MB; ++s)
+                if (s < m) acc = fma(fi[s], Zn[(size_t)s * ld + c], acc);
+            row[c] = acc;
+        }
+    }
+    __syncthreads();                                                       // all generic updates of this workgroup are issued
+    for (int j = 0; j < m; ++j) {
+        const int k = ks[j];
+        for (int i = row0 + tid; i < row1; i += NT) T[(size_t)i * ld + k] = Pn[(size_t)j * ld + i];           // column k
+        if (k >= row0 && k < row1)
+            for (int c = tid; c < ld; c += NT) T[(size_t)k * ld + c] = Pn[(size_t)j * ld + c];               // row k
+    }
+    __syncthreads();
+}
+
+// pivots per block such that the two [mb][ld] LDS images fit `budget` bytes
+inline int gj_block_size(int ld, size_t budget)
+{
+    int mb = (int)(budget / ((size_t)2 * ld * sizeof(double)));
+    if (mb > GJ_MB) mb = GJ_MB;
+    if (mb < 1) mb = 1;
+    return mb;
+}
+
+}  // namespace partls

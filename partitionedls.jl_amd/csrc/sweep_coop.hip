@@ -15,7 +15,7 @@
 //                the rows / columns of the pivoted variables from the final panel;
 //   4. one grid barrier.
 // So the grid synchronises once per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables).
-#include "common.h"
+#include "gj_panel.h"
 #include <hip/hip_cooperative_groups.h>
 
 namespace cg = cooperative_groups;
@@ -24,7 +24,7 @@ namespace partls {
 
 static constexpr int COOP_THREADS = 256;
 static constexpr int COOP_MAXWORDS = 16;
-static constexpr int COOP_MB = 16;
+static constexpr int COOP_MB = GJ_MB;
 
 __device__ __forceinline__ int coop_sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
 
@@ -110,56 +110,10 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
         for (int b0 = 0; b0 < nv; b0 += mb) {
             const int m = (nv - b0 < mb) ? nv - b0 : mb;
             const int *ks = s_viol + b0;
-            // ---- 1. panel: rows ks[j] of the tableau (= columns, by symmetry) ----------------------------------------------
-            for (int j = 0; j < m; ++j) {
-                const double *src = T + (size_t)ks[j] * ld;
-                for (int i = tid; i < ld; i += COOP_THREADS) Pn[(size_t)j * ld + i] = __builtin_nontemporal_load(&src[i]);
-            }
-            __syncthreads();
-            // ---- 2. redundant elimination of the panel (block-local barriers only) ---------------------------------------
-            for (int s = 0; s < m; ++s) {
-                const int k = ks[s];
-                if (tid < m) uj[tid] = Pn[(size_t)tid * ld + k];                 // pivot-row entries before the step
-                __syncthreads();
-                const double d = uj[s];
-                const bool ok = s_basic[k] || (d > p.piv_eps);                   // dependent column: rejected for the current basis
-                const double inv = ok ? 1.0 / d : 0.0, ainv = fabs(inv);
-                if (ok) {
-                    for (int i = tid; i < ld; i += COOP_THREADS) {
-                        const double zi = Pn[(size_t)s * ld + i];
-                        Zn[(size_t)s * ld + i] = zi;
-                        const double mi = -zi * inv;
-                        for (int j = 0; j < m; ++j) {
-                            if (j == s) continue;
-                            const double pji = Pn[(size_t)j * ld + i];
-                            Pn[(size_t)j * ld + i] = (i == k) ? uj[j] * ainv : fma(mi, uj[j], pji);
-                        }
-                        Pn[(size_t)s * ld + i] = (i == k) ? -inv : zi * ainv;
-                    }
-                }
-                if (tid == 0) dinv[s] = inv;
-                __syncthreads();
-            }
-            // ---- 3. fused rank-m update of the owned rows, then the pivoted rows / columns from the final panel ------------
-            for (int i = row0 + wave; i < row1; i += COOP_THREADS / 64) {
-                double *row = T + (size_t)i * ld;
-                for (int c = lane; c < ld; c += 64) {
-                    double acc = row[c];
-                    for (int s = 0; s < m; ++s) {
-                        const double f = dinv[s];
-                        if (f != 0.0) acc = fma(-Zn[(size_t)s * ld + i] * f, Zn[(size_t)s * ld + c], acc);
-                    }
-                    row[c] = acc;
-                }
-            }
-            __syncthreads();                                                       // all generic updates of this workgroup are issued
-            for (int j = 0; j < m; ++j) {
-                const int k = ks[j];
-                for (int i = row0 + tid; i < row1; i += COOP_THREADS) T[(size_t)i * ld + k] = Pn[(size_t)j * ld + i];   // column k
-                if (k >= row0 && k < row1)
-                    for (int c = tid; c < ld; c += COOP_THREADS) T[(size_t)k * ld + c] = Pn[(size_t)j * ld + c];       // row k
-            }
-            __syncthreads();
+            // ---- 1. panel, 2. redundant elimination (block-local barriers only), 3. fused update of the owned rows ------------
+            gj_panel_load<COOP_THREADS>(T, ld, ks, m, Pn, tid);
+            gj_panel_eliminate<COOP_THREADS>(Pn, Zn, dinv, uj, ks, m, ld, s_basic, p.piv_eps, tid);
+            gj_apply<COOP_THREADS>(T, ld, row0, row1, Pn, Zn, dinv, ks, m, tid);
             if (tid == 0) {
                 for (int j = 0; j < m; ++j) {
                     if (dinv[j] != 0.0) s_basic[ks[j]] ^= 1; else s_blocked[ks[j]] = 1;
@@ -188,9 +142,7 @@ hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s)
 {
     const int ld = p.n + 1;
     // pivots per block: two [mb][ld] LDS images within ~136 KB
-    int mb = (int)((size_t)136 * 1024 / ((size_t)2 * ld * sizeof(double)));
-    if (mb > COOP_MB) mb = COOP_MB;
-    if (mb < 1) mb = 1;
+    int mb = gj_block_size(ld, (size_t)136 * 1024);
     const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + 2 * COOP_MB * sizeof(double) + 2 * (size_t)p.n + 16;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_coop_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);

@@ -12,10 +12,12 @@
 // group's variables (plus a few neighbours) violate KKT: they are exchanged by block principal pivoting
 // (all violators at once; Kim & Park's finite-termination backup rule), one symmetric rank-1 sweep per variable:
 //        T_ij -= T_ik T_kj / d ,  T_ik = T_ik / |d| ,  T_kk = -1/d        (d = T_kk; the same formula enters and removes).
-// This kernel is the fully general, simple form: full (n+1)^2 tableau per workgroup in global scratch (L2 resident).
-// The register-resident production kernel is sweep_reg.hip; both share SweepParams and must agree bit-for-bit in
-// their decisions up to rounding.
-#include "common.h"
+// This kernel is the fully general form: full (n+1)^2 tableau per workgroup in global scratch.  With 256 concurrent
+// tableaus of 2 MB (n = 513) the passes over the tableau are HBM-bound, so the violators of a scan are exchanged in BLOCKS of up
+// to 16 pivots (gj_panel.h: panel of the pivot columns eliminated in LDS, then ONE fused rank-m pass over the tableau) instead
+// of one full pass per pivot.  The register-resident production kernels are sweep_blk.hip / sweep_reg.hip; all share
+// SweepParams and agree in their decisions up to rounding.
+#include "gj_panel.h"
 
 namespace partls {
 
@@ -28,16 +30,20 @@ __device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat)
     return 2 * __popcll(m & pat) - __popcll(m);
 }
 
-__global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams p)
+__global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams p, int mb)
 {
     const int n = p.n, ld = n + 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     extern __shared__ double smem[];
-    double *r = smem;                                             // pivot column, ld doubles
-    uint8_t *s_basic = reinterpret_cast<uint8_t *>(smem + ld);    // n bytes
+    double *Pn = smem;                                            // [mb][ld] panel: the block's pivot columns, all rows
+    double *Zn = Pn + (size_t)mb * ld;                            // [mb][ld] column s as of its own step
+    double *dinv = Zn + (size_t)mb * ld;                          // [GJ_MB] 1/d_s (0: rejected)
+    double *uj = dinv + GJ_MB;                                    // [GJ_MB] pivot-row entries of the current step
+    uint8_t *s_basic = reinterpret_cast<uint8_t *>(uj + GJ_MB);   // n bytes
     uint8_t *s_blocked = s_basic + n;                             // n bytes
     __shared__ unsigned long long s_inf[GEN_MAXWORDS];
-    __shared__ int s_skip;
+    __shared__ int s_viol[GEN_MAXWORDS * 64];
+    __shared__ int s_nv;
 
     double *T = p.scratch + (size_t)blockIdx.x * (size_t)ld * (size_t)ld;
     const int nwords = (n + 63) >> 6;
@@ -48,33 +54,6 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
 
     const int64_t total = p.g_end - p.g_begin;
     const int64_t nchains = (total + p.chain_len - 1) / p.chain_len;
-
-    // one symmetric principal pivot on variable k (uniform call)
-    auto pivot = [&](int k) -> bool {
-        for (int i = tid; i < ld; i += GEN_THREADS) r[i] = T[(size_t)k * ld + i];
-        __syncthreads();
-        const double d = r[k];
-        if (!s_basic[k] && !(d > p.piv_eps)) {                    // dependent column: Lawson–Hanson's rejection
-            __syncthreads();
-            if (tid == 0) s_blocked[k] = 1;
-            __syncthreads();
-            return false;
-        }
-        const double inv = 1.0 / d, ainv = 1.0 / fabs(d);
-        for (int i = wave; i < ld; i += GEN_THREADS / 64) {
-            const double ri = r[i], mi = -ri * inv;
-            double *row = T + (size_t)i * ld;
-            if (i == k) {
-                for (int j = lane; j < ld; j += 64) row[j] = (j == k) ? -inv : r[j] * ainv;
-            } else {
-                for (int j = lane; j < ld; j += 64) row[j] = (j == k) ? ri * ainv : fma(mi, r[j], row[j]);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_basic[k] ^= 1;
-        __syncthreads();
-        return true;
-    };
 
     for (int64_t chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
         const int64_t g0 = p.g_begin + chain * p.chain_len;
@@ -122,22 +101,33 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                 else if (patience > 0) { --patience; all = true; }
                 else all = false;                                  // backup rule: single pivot, largest index
                 if (++rounds > p.max_rounds) { ++nunconv; break; }
-                if (all) {
+                // the violator list of this round (ascending; the backup rule keeps only the last one), exchanged in blocks
+                if (tid == 0) {
+                    int nv = 0;
                     for (int w = 0; w < nwords; ++w) {
                         unsigned long long bits = s_inf[w];
-                        while (bits) {
-                            const int k = (w << 6) + __builtin_ctzll(bits);
-                            bits &= bits - 1;
-                            if (pivot(k)) { ++npiv; progress = true; }
-                        }
+                        while (bits) { s_viol[nv++] = (w << 6) + __builtin_ctzll(bits); bits &= bits - 1; }
                     }
-                } else {
-                    int k = -1;
-                    for (int w = nwords - 1; w >= 0 && k < 0; --w)
-                        if (s_inf[w]) k = (w << 6) + 63 - __builtin_clzll(s_inf[w]);
-                    if (pivot(k)) { ++npiv; progress = true; }
+                    if (!all) { s_viol[0] = s_viol[nv - 1]; nv = 1; }
+                    s_nv = nv;
                 }
                 __syncthreads();
+                const int nv = s_nv;
+                for (int b0 = 0; b0 < nv; b0 += mb) {
+                    const int m = (nv - b0 < mb) ? nv - b0 : mb;
+                    const int *ks = s_viol + b0;
+                    gj_panel_load<GEN_THREADS>(T, ld, ks, m, Pn, tid);
+                    const int acc = gj_panel_eliminate<GEN_THREADS>(Pn, Zn, dinv, uj, ks, m, ld, s_basic, p.piv_eps, tid);
+                    gj_apply<GEN_THREADS>(T, ld, 0, ld, Pn, Zn, dinv, ks, m, tid);
+                    if (tid == 0) {
+                        for (int j = 0; j < m; ++j) {
+                            if (dinv[j] != 0.0) s_basic[ks[j]] ^= 1; else s_blocked[ks[j]] = 1;
+                        }
+                    }
+                    if (acc) { npiv += (unsigned)acc; progress = true; }
+                    __threadfence_block();
+                    __syncthreads();
+                }
             }
             const double obj2 = T[(size_t)n * ld + n];
             const double obj = sqrt(obj2 > 0.0 ? obj2 : 0.0);
@@ -158,13 +148,17 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
     }
-    (void)s_skip;
 }
 
 hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s)
 {
-    const size_t shmem = (size_t)(p.n + 1) * sizeof(double) + 2 * (size_t)p.n + 16;
-    hipLaunchKernelGGL(sweep_generic_kernel, dim3(grid), dim3(GEN_THREADS), shmem, s, p);
+    const int ld = p.n + 1;
+    int mb = gj_block_size(ld, (size_t)136 * 1024);
+    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + 2 * GJ_MB * sizeof(double) + 2 * (size_t)p.n + 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_generic_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sweep_generic_kernel, dim3(grid), dim3(GEN_THREADS), shmem, s, p, mb);
     return hipGetLastError();
 }
 
