@@ -62,17 +62,36 @@ __device__ __forceinline__ void gj_apply(double *T, int ld, int row0, int row1, 
                                          const int *ks, int m, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
+    // Each wave owns whole rows; the row is walked in chunks of 8 x 64 columns with all eight loads issued before the first
+    // use: a single workgroup per CU has little memory-level parallelism otherwise (one dependent HBM latency per 64 elements).
+    constexpr int U = 8;
     for (int i = row0 + wave; i < row1; i += NT / 64) {
         double *row = T + (size_t)i * ld;
         double fi[GJ_MB];
 #pragma unroll
         for (int s = 0; s < GJ_MB; ++s) fi[s] = (s < m) ? -Zn[(size_t)s * ld + i] * dinv[s] : 0.0;     // 0 for rejected pivots
-        for (int c = lane; c < ld; c += 64) {
-            double acc = row[c];
+        for (int c0 = lane; c0 < ld; c0 += 64 * U) {
+            double acc[U];
 #pragma unroll
-            for (int s = 0; s < GJ_MB; ++s)
-                if (s < m) acc = fma(fi[s], Zn[(size_t)s * ld + c], acc);
-            row[c] = acc;
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + 64 * u;
+                acc[u] = (c < ld) ? __builtin_nontemporal_load(&row[c]) : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < GJ_MB; ++s) {
+                if (s < m) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int c = c0 + 64 * u;
+                        acc[u] = fma(fi[s], Zn[(size_t)s * ld + (c < ld ? c : 0)], acc[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + 64 * u;
+                if (c < ld) row[c] = acc[u];
+            }
         }
     }
     __syncthreads();                                                       // all generic updates of this workgroup are issued

@@ -22,7 +22,7 @@ namespace cg = cooperative_groups;
 
 namespace partls {
 
-static constexpr int COOP_THREADS = 256;
+static constexpr int COOP_THREADS = 1024;  // 16 waves per CU: the fused update is bound by memory latency, not by issue
 static constexpr int COOP_MAXWORDS = 16;
 static constexpr int COOP_MB = GJ_MB;
 

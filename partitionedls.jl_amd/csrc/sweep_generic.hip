@@ -21,7 +21,7 @@
 
 namespace partls {
 
-static constexpr int GEN_THREADS = 256;
+static constexpr int GEN_THREADS = 1024;   // 16 waves per CU: the fused update is bound by memory latency, not by issue
 static constexpr int GEN_MAXWORDS = 16;     // n <= 1024
 
 __device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat)
