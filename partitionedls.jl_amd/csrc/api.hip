@@ -1,6 +1,7 @@
 // api.hip — the C ABI of include/partls.h: host orchestration of the HIP kernels.  No CPU fallback: every compute
 // entry needs a HIP device and fails with PARTLS_ERR_NO_DEVICE / PARTLS_ERR_HIP otherwise.
 #include "ctx.h"
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -296,26 +297,44 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         if (w[(size_t)m] != 0.0 || (m == (int)M && free_intercept)) sup.push_back(m);
     const int p = (int)sup.size();
     if (p == 0) return PARTLS_OK;
-    // Cholesky of the regularised Gram on the support (host copy); give up quietly if it is not numerically SPD
-    std::vector<double> Lc((size_t)p * p, 0.0);
-    for (int i = 0; i < p; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double s = h_reg(c, sup[(size_t)i], sup[(size_t)j]);
-            for (int k = 0; k < j; ++k) s -= Lc[(size_t)i * p + k] * Lc[(size_t)j * p + k];
-            if (i == j) { if (!(s > 0.0)) return PARTLS_OK; Lc[(size_t)i * p + i] = std::sqrt(s); }
-            else Lc[(size_t)i * p + j] = s / Lc[(size_t)j * p + j];
-        }
     PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
     PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
     PARTLS_HIP_CHECK(c->gD.ensure((size_t)(M + 1) * sizeof(double)));
     std::vector<double> g((size_t)M + 1), d((size_t)p);
+    std::vector<double> Lc((size_t)p * p, 0.0);
+    // row-oriented Cholesky of the regularised Gram on the support (host copy); the inner products carry four independent
+    // partial sums so the compiler can vectorise them (the support is all of [features, intercept] in the typical case:
+    // p^3 / 6 multiply-adds).  It runs while the device computes the first residual and gradient.
+    auto factorise = [&]() -> bool {
+        auto dot4 = [](const double *__restrict a, const double *__restrict b, int nk) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = 0;
+            for (; k + 3 < nk; k += 4) { s0 += a[k] * b[k]; s1 += a[k + 1] * b[k + 1]; s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3]; }
+            for (; k < nk; ++k) s0 += a[k] * b[k];
+            return (s0 + s1) + (s2 + s3);
+        };
+        for (int i = 0; i < p; ++i) {
+            double *Li = &Lc[(size_t)i * p];
+            for (int j = 0; j <= i; ++j) {
+                const double *Lj = &Lc[(size_t)j * p];
+                const double s = h_reg(c, sup[(size_t)i], sup[(size_t)j]) - dot4(Li, Lj, j);
+                if (i == j) { if (!(s > 0.0)) return false; Li[i] = std::sqrt(s); }
+                else Li[j] = s / Lj[j];
+            }
+        }
+        return true;
+    };
+    const auto r0 = std::chrono::steady_clock::now();
     for (int it = 0; it < steps; ++it) {
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
         PARTLS_HIP_CHECK(launch_residual(c->dX, N, M, c->ldX, nullptr, c->wdev.as<double>(), w[(size_t)M], nullptr, 1024,
                                          c->yhatD.as<double>(), c->stream));
         PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, c->yhatD.as<double>(), c->gD.as<double>(), c->stream));
+        bool spd = true;
+        if (it == 0) spd = factorise();                      // overlaps with the kernels just queued (the copy below waits for them)
         PARTLS_HIP_CHECK(hipMemcpyAsync(g.data(), c->gD.p, (size_t)(M + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
         if (c->eta != 0.0) {                                 // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
             for (int64_t k = 0; k <= c->K; ++k) {
                 double gs = 0.0;
@@ -339,6 +358,9 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         // round-off for every problem the Gram path can solve at all
         if (dn <= 1e-18 * wn) break;
     }
+    if (getenv("PARTLS_FINISH_TRACE"))
+        fprintf(stderr, "[refine] support %d: %.3f ms (factorisation overlapped with the first residual / gradient pass)\n", p,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
     return PARTLS_OK;
 }
 
@@ -526,15 +548,23 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     std::vector<double> sols, obj2, w;
     unsigned long long unconv = 0;
     t_begin(c, PARTLS_T_FINISH);
+    const auto f0 = std::chrono::steady_clock::now();
     partls_status st = solve_nodes(c, {(uint64_t)pattern & kmask}, {0}, {0}, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
+    const auto f1 = std::chrono::steady_clock::now();
     unscale_solution(c, sols.data(), w);
     st = refine_solution(c, w, !c->faithful);             // QR-level accuracy of the winner on ill-conditioned data
     if (st != PARTLS_OK) return st;
+    const auto f2 = std::chrono::steady_clock::now();
     uint64_t full = (uint64_t)pattern & kmask;
     if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
     else full = (uint64_t)pattern;
     st = data_objective(c, w, opt);
+    if (getenv("PARTLS_FINISH_TRACE")) {
+        const auto f3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[finish] node solve %.3f ms, refine %.3f ms, data objective %.3f ms\n", ms(f0, f1), ms(f1, f2), ms(f2, f3));
+    }
     t_end(c, PARTLS_T_FINISH);
     if (st != PARTLS_OK) return st;
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
