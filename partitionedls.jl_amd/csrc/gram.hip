@@ -118,7 +118,7 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ X, int64_t 
         }
 }
 
-__global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
+__global__ __launch_bounds__(256, 4) void gram_kernel(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
                                                    const double *__restrict__ y, double *__restrict__ slab, int ldg,
                                                    int chunk_rows, int S, int np)
 {
