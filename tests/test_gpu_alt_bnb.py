@@ -119,3 +119,21 @@ def test_alt_and_opt_beyond_register_kernel(partls, oracle):
     assert abs(repo.opt - ro["opt"]) <= 1e-9 * max(1.0, ro["opt"])
     np.testing.assert_allclose(mo.α, ro["alpha"], atol=1e-7)
     np.testing.assert_allclose(mo.β, ro["beta"], atol=1e-7)
+
+
+def test_alt_determinism_like_the_reference_suite(partls):
+    """runtests.jl:102-121 — ten fits of Alt with rng=123 on a 1000 x 10 regression with two groups of five give the same
+    optimum (|Δ| <= 1e-6); make_regression is replaced by a fixed numpy draw (MLJBase is not available here)."""
+    rng = np.random.default_rng(123)
+    X = rng.standard_normal((1000, 10))
+    y = X @ rng.standard_normal(10) + 0.1 * rng.standard_normal(1000)
+    P = np.zeros((10, 2), dtype=np.int64); P[:5, 0] = 1; P[5:, 1] = 1
+    last = None
+    for _ in range(10):
+        model, _, rep = partls.fit(partls.Alt, X, y, P, ϵ=1e-3, T=100, rng=123)
+        y_pred = partls.predict(model, X)
+        assert np.all(np.isfinite(y_pred))
+        if last is None:
+            last = rep.opt
+        else:
+            assert abs(rep.opt - last) <= 1e-6
