@@ -107,6 +107,11 @@ partls_status partls_fit_bnb(partls_ctx *ctx, const double *X, int64_t N, int64_
 partls_status partls_predict(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX,
                              const int64_t *P, int64_t K, int64_t ldP, const double *alpha, const double *beta, double t,
                              double *yhat);
+/* The same with X (N x M, ldX) and yhat (N) resident in HBM: DEVICE pointers that stay owned by the caller (the large-N
+ * form of PartitionedLS.jl:132-134 — no PCIe copy of X; P, alpha, beta stay host pointers, they are M*K numbers). */
+partls_status partls_predict_device(partls_ctx *ctx, const double *dX, int64_t N, int64_t M, int64_t ldX,
+                                    const int64_t *P, int64_t K, int64_t ldP, const double *alpha, const double *beta,
+                                    double t, double *dyhat);
 
 /* ---- synthetic inputs of BASELINE.md §4, generated in HBM (bit-identical to oracle_synth on the host) -----------------
  * dX: device N x D (ld = N), dy: device N; wstar: HOST D doubles (alpha*_j beta*_g(j), from partls_synth_truth). */
@@ -125,6 +130,9 @@ typedef enum {
 partls_status partls_get_timing(const partls_ctx *ctx, partls_timer which, double *ms);
 /* principal pivots executed by the last partls_opt_sweep (fp64 flop accounting: each pivot updates the whole symmetric tableau) */
 partls_status partls_get_pivots(const partls_ctx *ctx, int64_t *pivots);
+/* entering pivots the last partls_opt_sweep refused under the leave-one-out dependence rule (0 on well-conditioned data; a
+ * large count says the data are rank deficient on the unit-diagonal scale — see DESIGN.md §4, numerical notes) */
+partls_status partls_get_vetoes(const partls_ctx *ctx, int64_t *vetoes);
 /* debugging / tests: copy the Gram products of the prepared problem to the host: G ((M+2) x (M+2), column-major,
  * variables ordered [features, intercept, y]), i.e. G, c = G[:, M+1], yy = G[M+1, M+1], after η has been applied. */
 partls_status partls_get_gram(const partls_ctx *ctx, double *G_aug);

@@ -10,9 +10,9 @@ All arithmetic runs in libpartls_hip.so (hand-written HIP for gfx950) through th
 there is no CPU fallback — importing works anywhere, computing needs an MI355X and raises otherwise.
 """
 from .api import (Alt, BnB, Context, Opt, PartLSFitResult, PartlsError, Report, build_library, default_context, fit,
-                  homogeneousCoords, library_path, predict, regularizeProblem, synth_truth)
+                  homogeneousCoords, library_path, predict, predict_device, regularizeProblem, synth_truth)
 from . import _lib as lowlevel
 from . import dist
 
 __all__ = ["fit", "predict", "PartLSFitResult", "Opt", "Alt", "BnB", "homogeneousCoords", "regularizeProblem",
-           "PartlsError", "Report", "build_library", "library_path", "lowlevel", "Context", "default_context", "synth_truth", "dist"]
+           "PartlsError", "Report", "build_library", "library_path", "lowlevel", "Context", "default_context", "synth_truth", "dist", "predict_device"]

@@ -38,11 +38,14 @@ SYMBOLS = [
     ("partls_alt_prepared", C.c_int, [C.c_void_p, C.c_double, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     ("partls_bnb_prepared", C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
     ("partls_predict", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, _i64, _i64, _dp, _dp, C.c_double, _dp]),
+    ("partls_predict_device", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, _i64, _i64, _dp, _dp, C.c_double,
+                                        C.c_void_p]),
     ("partls_synth_truth", C.c_int, [C.c_uint64, _i64, _i64, _ip, _dp]),
     ("partls_synth_device", C.c_int, [C.c_void_p, C.c_uint64, _i64, _i64, _dp, C.c_void_p, C.c_void_p]),
     ("partls_get_timing", C.c_int, [C.c_void_p, C.c_int, _dp]),
     ("partls_get_gram", C.c_int, [C.c_void_p, _dp]),
     ("partls_get_pivots", C.c_int, [C.c_void_p, _ip]),
+    ("partls_get_vetoes", C.c_int, [C.c_void_p, _ip]),
 ]
 
 _lib = None
@@ -92,6 +95,8 @@ def lib():
         _preload_torch_hip_runtime()
         l = C.CDLL(SO_PATH)
         for name, res, args in SYMBOLS:
+            if os.environ.get("PARTLS_LIB") and not hasattr(l, name):
+                continue                   # diagnostic A/B builds of older sources may lack the newest entry points
             f = getattr(l, name)           # AttributeError here = header/library mismatch
             f.restype = res
             f.argtypes = args

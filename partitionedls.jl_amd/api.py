@@ -4,7 +4,9 @@ fit(Opt|Alt|BnB, X, y, P; η, ...) / predict keep the reference's names, argumen
 `(PartLSFitResult, nothing, report)` and error behaviour; the arithmetic runs on the MI355X through the C ABI
 (include/partls.h).  Nothing here computes on the CPU beyond argument marshalling.
 """
+import atexit
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -79,8 +81,13 @@ class Context:
         self._h = C.c_void_p()
         _check(L.lib().partls_create(int(device), C.byref(self._h)))
         self.device = device
+        self.generation = 0          # bumped by every prepare: lazily rebuilt results check it (see _Solutions)
+        _live_contexts.add(self)
 
     def close(self):
+        """Release the device objects now.  Also run for every live context by an atexit hook, i.e. BEFORE interpreter
+        finalisation and before the HIP runtime (or a profiler layered on it) tears itself down — a context destroyed later,
+        from a module-global's __del__ during exit(), made HIP calls into a dead runtime (round-1 rocprofv3 crash)."""
         if self._h:
             L.lib().partls_destroy(self._h)
             self._h = C.c_void_p()
@@ -99,6 +106,7 @@ class Context:
         P = np.asfortranarray(P, dtype=np.int64)
         N, M = X.shape
         self._shape = (N, M, P.shape[1])
+        self.generation += 1
         _check(L.lib().partls_opt_prepare(self._h, X.ctypes.data, N, M, N, y.ctypes.data, 0, P.ctypes.data, P.shape[1],
                                           P.shape[0], float(eta), int(flags)))
 
@@ -106,6 +114,7 @@ class Context:
         """dX_ptr, dy_ptr: raw device addresses (e.g. torch tensor .data_ptr()) that stay owned by the caller."""
         P = np.asfortranarray(P, dtype=np.int64)
         self._shape = (N, M, P.shape[1])
+        self.generation += 1
         _check(L.lib().partls_opt_prepare(self._h, C.c_void_p(dX_ptr), N, M, ldX, C.c_void_p(dy_ptr), 1, P.ctypes.data,
                                           P.shape[1], P.shape[0], float(eta), int(flags)))
 
@@ -165,6 +174,11 @@ class Context:
         _check(L.lib().partls_get_pivots(self._h, C.byref(n)))
         return n.value
 
+    def vetoes(self):
+        n = C.c_int64()
+        _check(L.lib().partls_get_vetoes(self._h, C.byref(n)))
+        return n.value
+
     def gram(self):
         N, M, K = self._shape
         G = np.zeros((M + 2, M + 2), order="F")
@@ -185,6 +199,17 @@ def synth_truth(seed, D, K):
 
 
 _default_ctx = {}
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all_contexts():
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    _default_ctx.clear()
 
 
 def default_context(device=0):
@@ -239,6 +264,7 @@ class _Solutions:
 
     def __init__(self, ctx, all_opt, P):
         self._ctx, self._all, self._P = ctx, all_opt, P
+        self._gen = ctx.generation       # the shared context may be re-prepared by a later fit: detect, never mis-answer
 
     def __len__(self):
         return len(self._all)
@@ -246,6 +272,9 @@ class _Solutions:
     def __getitem__(self, b):
         if b < 0:
             b += len(self)
+        if self._ctx.generation != self._gen:
+            raise PartlsError(L.ERR_STATE, "the context of these solutions has been prepared for another problem since; "
+                                           "materialise the models you need (list(report.solutions)) before the next fit")
         a, bt, t, opt, _ = self._ctx.opt_finish(b)
         return float(self._all[b]), PartLSFitResult(a, bt, t, self._P)
 
@@ -302,12 +331,14 @@ def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="n
             raise ValueError("alpha0 must have M+1 and beta0 K+1 entries")
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double(); it = C.c_int64()
+        ctx.generation += 1
         _check(lib.partls_fit_alt(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v, eps_v,
                                   int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(it)))
         return PartLSFitResult(a, b, t.value, Pout), None, Report(opt=o.value, iters=it.value)
     if alg is BnB:
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double(); no = C.c_int64()
+        ctx.generation += 1
         _check(lib.partls_fit_bnb(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v,
                                   _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
         return PartLSFitResult(a, b, t.value, Pout), None, Report(opt=o.value, nopen=no.value)
@@ -338,3 +369,15 @@ def predict(*args, device=0):
     _check(L.lib().partls_predict(ctx._h, Xf.ctypes.data, N, M, N, Pf.ctypes.data, Pf.shape[1], M, _dp(a), _dp(b),
                                   float(t), _dp(yh)))
     return yh
+
+
+def predict_device(model, dX_ptr, N, ldX, dyhat_ptr, device=0):
+    """predict with X (N x M, column-major, leading dimension ldX) and yhat (N) resident in HBM: raw device addresses (e.g.
+    torch tensor .data_ptr()) that stay owned by the caller.  PartitionedLS.jl:132-134 without the PCIe copy of X."""
+    Pf = np.asfortranarray(model.P, dtype=np.int64)
+    a = np.ascontiguousarray(model.α, dtype=np.float64)
+    b = np.ascontiguousarray(model.β, dtype=np.float64)
+    M, K = Pf.shape
+    ctx = default_context(device)
+    _check(L.lib().partls_predict_device(ctx._h, C.c_void_p(dX_ptr), int(N), M, int(ldX), Pf.ctypes.data, K, M, _dp(a), _dp(b),
+                                         float(model.t), C.c_void_p(dyhat_ptr)))

@@ -97,11 +97,12 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     PARTLS_HIP_CHECK(launch_finite_check(c->dX, N, M, c->ldX, c->dy, c->flag.as<int>(), c->stream));
 
     // Gram products (fp64 MFMA)
-    const size_t slabd = gram_slab_doubles(N, M, &c->chunks, &c->ldg);
+    const size_t slabd = gram_slab_doubles(N, M, c->knobs.gram_S, c->knobs.gram_cr, &c->chunks, &c->ldg);
     PARTLS_HIP_CHECK(c->slab.ensure(slabd * sizeof(double)));
     PARTLS_HIP_CHECK(c->G.ensure((size_t)c->ldg * c->ldg * sizeof(double)));
     t_begin(c, PARTLS_T_GRAM);
-    PARTLS_HIP_CHECK(launch_gram(c->dX, N, M, c->ldX, c->dy, c->slab.as<double>(), c->chunks, c->ldg, c->G.as<double>(), c->stream));
+    PARTLS_HIP_CHECK(launch_gram(c->dX, N, M, c->ldX, c->dy, c->slab.as<double>(), c->chunks, c->ldg, c->knobs.gram_S, c->knobs.gram_cr,
+                                 c->G.as<double>(), c->stream));
     t_end(c, PARTLS_T_GRAM);
 
     // tableau variables, grouped by partition (stable sort on the lowest group a variable belongs to) so that the
@@ -133,21 +134,6 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
         PARTLS_HIP_CHECK(launch_layout_reg(c->Tfull.as<double>(), c->n, c->T, c->T0reg.as<double>(), c->stream));
     }
     t_end(c, PARTLS_T_PREP);
-    // two-level sweep: the leading groups whose variables (and nobody else's) all sit among the first tableau variables
-    c->low_groups = 0;
-    if (c->use_reg && c->T >= 3) {
-        const int nsv = sweep_two_small_vars();
-        int v = 0;
-        for (; v < c->kbits - 1 && v < 2; ++v) {     // 2^v patterns per block = one per team of the two-level kernel
-            bool ok = true;
-            for (int i = nsv; i < c->n && ok; ++i) ok = !((c->mask_tab[(size_t)i] >> v) & 1ULL);
-            if (!ok) break;
-        }
-        const char *lg = getenv("PARTLS_LOW_GROUPS");
-        if (lg && atoi(lg) < v) v = atoi(lg) < 0 ? 0 : atoi(lg);
-        c->low_groups = v;
-    }
-
     c->hG.resize((size_t)c->ldg * c->ldg);
     c->hScale.resize((size_t)c->n);
     int bad = 0;
@@ -158,9 +144,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     t_collect(c);
     if (bad) { set_error("X or y contains NaN/Inf"); return PARTLS_ERR_NONFINITE; }
     const double yy = c->hG[(size_t)(M + 1) * c->ldg + (M + 1)];
-    const char *tolenv = getenv("PARTLS_TOL_REL");
-    const double tolrel = tolenv ? atof(tolenv) : 1e-11;
-    c->tol = tolrel * std::sqrt(yy > 0.0 ? yy : 0.0);
+    c->tol = c->knobs.tol_rel * std::sqrt(yy > 0.0 ? yy : 0.0);
     if (!(c->tol > 0.0)) c->tol = 1e-300;
     c->prepared = true;
     return PARTLS_OK;
@@ -170,16 +154,6 @@ static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
 {
     if (c->use_reg) {
         p.T0 = c->T0reg.as<double>();
-        const char *kv = getenv("PARTLS_KERNEL");          // "reg" = rank-1 register kernel (A/B); default = blocked pivots
-        if (kv && strcmp(kv, "reg") == 0) return launch_sweep_reg(p, c->T, grid, c->stream);
-        // two-level sweep (sweep_two.hip) for pattern chains; "blk" = single-level blocked kernel (A/B, and all node solves)
-        // (experimental, opt-in with PARTLS_KERNEL=two until it beats the single-level kernel)
-        if (!p.node_pat && c->low_groups > 0 && kv && strcmp(kv, "two") == 0) {
-            p.low_groups = c->low_groups;
-            const char *ec = getenv("PARTLS_LOW_ECAP");        // test hook: 0 forces the classical fallback on every discovery
-            p.low_ecap = ec ? atoi(ec) : 8;
-            return launch_sweep_two(p, c->T, grid, c->stream);
-        }
         return launch_sweep_blk(p, c->T, grid, c->stream);
     }
     p.T0 = c->Tfull.as<double>();
@@ -205,7 +179,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
     PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
-    const bool coop = !c->use_reg && cnt == 1 && !getenv("PARTLS_NO_COOP");
+    const bool coop = !c->use_reg && cnt == 1 && !c->knobs.no_coop;
     if (coop) {
         const size_t need = ((size_t)ld * ld + (size_t)n / 8 + 2) * sizeof(double);      // tableau + basis flags
         if (c->scratch.bytes < need) c->coop_state_valid = false;
@@ -229,6 +203,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
     p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
     p.n_unconverged = c->counters.as<unsigned long long>();
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
+    p.n_vetoes = c->counters.as<unsigned long long>() + 2;
     p.node_pat = c->nodePat.as<uint64_t>(); p.node_free = c->nodeFree.as<uint64_t>(); p.node_zero = c->nodeZero.as<uint64_t>();
     p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
     if (coop) {
@@ -358,7 +333,7 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         // round-off for every problem the Gram path can solve at all
         if (dn <= 1e-18 * wn) break;
     }
-    if (getenv("PARTLS_FINISH_TRACE"))
+    if (c->knobs.finish_trace)
         fprintf(stderr, "[refine] support %d: %.3f ms (factorisation overlapped with the first residual / gradient pass)\n", p,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count());
     return PARTLS_OK;
@@ -419,10 +394,26 @@ partls_status partls_create(int device, partls_ctx **out)
     partls_ctx *c = new (std::nothrow) partls_ctx();
     if (!c) { set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
     c->device = device;
-    PARTLS_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int w = 0; w < PARTLS_T_COUNT; ++w) {
-        PARTLS_HIP_CHECK(hipEventCreate(&c->ev0[w]));
-        PARTLS_HIP_CHECK(hipEventCreate(&c->ev1[w]));
+    // environment knobs: read here, once (the compute entries never call getenv)
+    if (const char *e = getenv("PARTLS_TOL_REL")) c->knobs.tol_rel = atof(e);
+    if (const char *e = getenv("PARTLS_CHAIN_LEN")) c->knobs.chain_len = atoll(e);
+    if (const char *e = getenv("PARTLS_GRID")) c->knobs.grid = atoll(e);
+    if (const char *e = getenv("PARTLS_GRAM_S")) c->knobs.gram_S = atoi(e);
+    if (const char *e = getenv("PARTLS_GRAM_CR")) c->knobs.gram_cr = atoi(e);
+    c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
+    c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
+    c->knobs.alt_trace = getenv("PARTLS_ALT_TRACE") != nullptr;
+    c->knobs.print_stamps = getenv("PARTLS_PRINT_STAMPS") != nullptr;
+    // a failure below must not leak the context (or the objects already created)
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int w = 0; w < PARTLS_T_COUNT && e == hipSuccess; ++w) {
+        e = hipEventCreate(&c->ev0[w]);
+        if (e == hipSuccess) e = hipEventCreate(&c->ev1[w]);
+    }
+    if (e != hipSuccess) {
+        set_error("partls_create: stream / event creation failed: %s", hipGetErrorString(e));
+        partls_destroy(c);
+        return PARTLS_ERR_HIP;
     }
     *out = c;
     return PARTLS_OK;
@@ -431,14 +422,23 @@ partls_status partls_create(int device, partls_ctx **out)
 void partls_destroy(partls_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
-                      &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
-                      &c->flag, &c->yhatD, &c->gD, &c->nodePat, &c->nodeFree, &c->nodeZero, &c->nodeSol, &c->nodeObj};
-    for (DevBuf *b : bufs) b->release();
-    for (int w = 0; w < PARTLS_T_COUNT; ++w) { (void)hipEventDestroy(c->ev0[w]); (void)hipEventDestroy(c->ev1[w]); }
-    (void)hipStreamDestroy(c->stream);
+    // At process exit the HIP runtime (or a profiler layered on it) may already be torn down when a late destructor gets
+    // here: touch the device only while the runtime still answers, otherwise just drop the host object.
+    int ndev = 0;
+    const bool alive = hipGetDeviceCount(&ndev) == hipSuccess && ndev > c->device && hipSetDevice(c->device) == hipSuccess;
+    if (alive) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
+                          &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
+                          &c->flag, &c->yhatD, &c->gD, &c->nodePat, &c->nodeFree, &c->nodeZero, &c->nodeSol, &c->nodeObj,
+                          &c->predX, &c->predY};
+        for (DevBuf *b : bufs) b->release();
+        for (int w = 0; w < PARTLS_T_COUNT; ++w) {
+            if (c->ev0[w]) (void)hipEventDestroy(c->ev0[w]);
+            if (c->ev1[w]) (void)hipEventDestroy(c->ev1[w]);
+        }
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 
@@ -467,14 +467,12 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     }
     const int n = c->n, ld = n + 1;
     const int64_t total = g_end - g_begin;
-    const char *cl = getenv("PARTLS_CHAIN_LEN");
-    int64_t chain_len = cl ? atoll(cl) : (c->use_reg ? 512 : 64);
+    int64_t chain_len = c->knobs.chain_len > 0 ? c->knobs.chain_len : (c->use_reg ? 512 : 64);
     if (chain_len < 1) chain_len = 1;
     // keep every CU busy on small problems: at least ~2 chains per CU when there are enough patterns
     while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
     const int64_t nchains = (total + chain_len - 1) / chain_len;
-    const char *ge = getenv("PARTLS_GRID");
-    int grid = (int)std::min<int64_t>(nchains, ge ? atoll(ge) : (c->use_reg ? 4096 : 1024));
+    int grid = (int)std::min<int64_t>(nchains, c->knobs.grid > 0 ? c->knobs.grid : (c->use_reg ? 4096 : 1024));
     if (grid < 1) grid = 1;
 
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * std::max(grid, 4096)));
@@ -495,7 +493,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
     p.n_unconverged = c->counters.as<unsigned long long>();
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
-    p.n_small_pivots = c->counters.as<unsigned long long>() + 2;
+    p.n_vetoes = c->counters.as<unsigned long long>() + 2;
 
     t_begin(c, PARTLS_T_SWEEP);
     PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
@@ -514,16 +512,13 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
     c->last_pivots = cnt[1];
-    c->last_small_pivots = cnt[2];
-    if (getenv("PARTLS_PRINT_STAMPS")) {                 // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
+    c->last_vetoes = cnt[2];
+    if (c->knobs.print_stamps) {                         // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
         double st[32] = {0};
         if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[partls stamps] scan: pre %.0f barrier %.0f post %.0f | gather: work %.0f barrier %.0f | panel: work %.0f barrier %.0f | "
-                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu || two-level: pre %.0f build %.0f small-solve %.0f verify %.0f "
-                            "low-gather %.0f small pivots %llu\n",
-                    st[9], st[10], st[0], st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1], st[7], st[12], st[13], st[14],
-                    st[15], cnt[2]);
-        fprintf(stderr, "[partls stamps] lockstep step: choose %.0f publish %.0f barrier %.0f update %.0f | steps %.0f\n", st[16], st[17], st[18], st[19], st[24]);
+                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu\n",
+                    st[9], st[10], st[0], st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1]);
     }
     double bobj = INFINITY;
     int64_t bpat = -1;
@@ -560,7 +555,7 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
     else full = (uint64_t)pattern;
     st = data_objective(c, w, opt);
-    if (getenv("PARTLS_FINISH_TRACE")) {
+    if (c->knobs.finish_trace) {
         const auto f3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[finish] node solve %.3f ms, refine %.3f ms, data objective %.3f ms\n", ms(f0, f1), ms(f1, f2), ms(f2, f3));
@@ -616,8 +611,10 @@ partls_status partls_fit_opt(partls_ctx *c, const double *X, int64_t N, int64_t 
     return PARTLS_OK;
 }
 
-partls_status partls_predict(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const int64_t *P, int64_t K,
-                             int64_t ldP, const double *alpha, const double *beta, double t, double *yhat)
+// predict: w_m = sum_k P[m,k] alpha_m beta_k on the host (M*K flops), yhat = X w + t on the device (one pass over X)
+static partls_status predict_common(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, int x_on_device,
+                                    const int64_t *P, int64_t K, int64_t ldP, const double *alpha, const double *beta, double t,
+                                    double *yhat)
 {
     partls_status st = check_common(c, X, N, M, ldX, P, K, ldP);
     if (st != PARTLS_OK) return st;
@@ -633,20 +630,36 @@ partls_status partls_predict(partls_ctx *c, const double *X, int64_t N, int64_t 
         }
         w[(size_t)m] = s;
     }
-    DevBuf dX, dyh, dw;
-    partls_status rc = PARTLS_OK;
-    do {
-        if (dX.ensure((size_t)N * M * sizeof(double)) != hipSuccess || dyh.ensure((size_t)N * sizeof(double)) != hipSuccess ||
-            dw.ensure((size_t)M * sizeof(double)) != hipSuccess) { set_error("hipMalloc failed in partls_predict"); rc = PARTLS_ERR_HIP; break; }
-        if (hipMemcpy2DAsync(dX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double), (size_t)N * sizeof(double),
-                             (size_t)M, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-            hipMemcpyAsync(dw.p, w.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) { set_error("H2D copy failed"); rc = PARTLS_ERR_HIP; break; }
-        if (launch_residual(dX.as<double>(), N, M, N, nullptr, dw.as<double>(), t, nullptr, 1024, dyh.as<double>(), c->stream) != hipSuccess) { set_error("predict kernel launch failed"); rc = PARTLS_ERR_HIP; break; }
-        if (hipMemcpyAsync(yhat, dyh.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipStreamSynchronize(c->stream) != hipSuccess) { set_error("D2H copy failed"); rc = PARTLS_ERR_HIP; break; }
-    } while (0);
-    dX.release(); dyh.release(); dw.release();
-    return rc;
+    PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const double *dX = X;
+    int64_t ld = ldX;
+    double *dyh = yhat;
+    if (!x_on_device) {
+        PARTLS_HIP_CHECK(c->predX.ensure((size_t)N * M * sizeof(double)));
+        PARTLS_HIP_CHECK(c->predY.ensure((size_t)N * sizeof(double)));
+        PARTLS_HIP_CHECK(hipMemcpy2DAsync(c->predX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double),
+                                          (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, c->stream));
+        dX = c->predX.as<double>(); ld = N; dyh = c->predY.as<double>();
+    }
+    PARTLS_HIP_CHECK(launch_residual(dX, N, M, ld, nullptr, c->wdev.as<double>(), t, nullptr, 1024, dyh, c->stream));
+    if (!x_on_device)
+        PARTLS_HIP_CHECK(hipMemcpyAsync(yhat, c->predY.p, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (!x_on_device) { c->predX.release(); c->predY.release(); }    // a prediction set is not retained
+    return PARTLS_OK;
+}
+
+partls_status partls_predict(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const int64_t *P, int64_t K,
+                             int64_t ldP, const double *alpha, const double *beta, double t, double *yhat)
+{
+    return predict_common(c, X, N, M, ldX, 0, P, K, ldP, alpha, beta, t, yhat);
+}
+
+partls_status partls_predict_device(partls_ctx *c, const double *dX, int64_t N, int64_t M, int64_t ldX, const int64_t *P,
+                                    int64_t K, int64_t ldP, const double *alpha, const double *beta, double t, double *dyhat)
+{
+    return predict_common(c, dX, N, M, ldX, 1, P, K, ldP, alpha, beta, t, dyhat);
 }
 
 partls_status partls_synth_truth(uint64_t seed, int64_t D, int64_t K, int64_t *P, double *wstar)
@@ -695,6 +708,13 @@ partls_status partls_get_pivots(const partls_ctx *c, int64_t *pivots)
 {
     if (!c || !pivots) { set_error("partls_get_pivots: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *pivots = (int64_t)c->last_pivots;
+    return PARTLS_OK;
+}
+
+partls_status partls_get_vetoes(const partls_ctx *c, int64_t *vetoes)
+{
+    if (!c || !vetoes) { set_error("partls_get_vetoes: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *vetoes = (int64_t)c->last_vetoes;
     return PARTLS_OK;
 }
 

@@ -40,9 +40,7 @@ struct SweepParams {
     int64_t *best_pat;           // [gridDim.x] its pattern index (lexicographic tie-break on the index)
     unsigned long long *n_unconverged;   // patterns that hit max_rounds
     unsigned long long *n_pivots;        // total pivots on the (n+1)^2 tableau (diagnostics / flop accounting)
-    unsigned long long *n_small_pivots;  // two-level kernel: pivots on the small (41 x 41) tableau
-    int low_groups;              // two-level kernel: groups 0..low_groups-1 are enumerated on the small tableau (0 = off)
-    int low_ecap;                // two-level kernel: discovered variables allowed per block (<= 8; fewer forces the classical fallback)
+    unsigned long long *n_vetoes;        // entering pivots refused by the leave-one-out rule (diagnostics)
     // Node mode (Alt alpha-steps, BnB node bounds): when node_pat != nullptr chain c is ONE subproblem with its own
     // pattern node_pat[c], free groups node_free[c] (no sign constraint: BnB's relaxed groups, BnB.jl:70-79) and zero
     // groups node_zero[c] (multiplier 0, e.g. beta_k == 0 in Alt.jl:80-81).  chain_len must be 1.  Outputs per node:
@@ -60,10 +58,7 @@ struct SweepParams {
 
 // launchers (each returns hipError_t of the launch)
 hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);
-hipError_t launch_sweep_reg(const SweepParams &p, int T, int grid, hipStream_t s);
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s);
-hipError_t launch_sweep_two(const SweepParams &p, int T, int grid, hipStream_t s);   // chain mode only (sweep_two.hip)
-int        sweep_two_small_vars();                       // variables 0..this-1 form the preseeded small set
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 272)
 bool       sweep_reg_supported(int n);
 int        sweep_reg_tiles(int n);
@@ -71,9 +66,10 @@ size_t     sweep_reg_t0_doubles(int T);                  // size of the tile-cyc
 hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, hipStream_t s);
 
 // gram build: G_aug = Z'Z with Z = [X 1 y]  (n_aug = M + 2), full symmetric, ld = ldg (multiple of 64)
-size_t     gram_slab_doubles(int64_t N, int64_t M, int *chunks_out, int *ldg_out);
+// (gram_S / gram_cr: tuning overrides read once at partls_create, 0 = automatic)
+size_t     gram_slab_doubles(int64_t N, int64_t M, int gram_S, int gram_cr, int *chunks_out, int *ldg_out);
 hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, double *slab, int chunks,
-                       int ldg, double *G, hipStream_t s);
+                       int ldg, int gram_S, int gram_cr, double *G, hipStream_t s);
 
 // tableau prep: B = regularised (and, free-intercept mode, intercept-eliminated) Gram; Tfull = unit-diagonal scaled
 // perm[i] = augmented-Gram index of tableau variable i (variables are grouped by partition so a flip touches few tiles)

@@ -22,8 +22,21 @@ struct DevBuf {
 
 }  // namespace partls
 
+// Tuning / diagnostic knobs, read from the environment ONCE at partls_create (never on the per-call path).
+struct partls_knobs {
+    double tol_rel = 1e-11;      // PARTLS_TOL_REL: KKT tolerance relative to ||y||
+    long long chain_len = 0;     // PARTLS_CHAIN_LEN: patterns per Gray chain (0 = automatic)
+    long long grid = 0;          // PARTLS_GRID: workgroups of the sweep (0 = automatic)
+    int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
+    bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    bool finish_trace = false;   // PARTLS_FINISH_TRACE
+    bool alt_trace = false;      // PARTLS_ALT_TRACE
+    bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
+};
+
 struct partls_ctx {
     int device = 0;
+    partls_knobs knobs;
     hipStream_t stream = nullptr;
     hipEvent_t ev0[PARTLS_T_COUNT] = {}, ev1[PARTLS_T_COUNT] = {};
     bool timed[PARTLS_T_COUNT] = {};
@@ -42,7 +55,7 @@ struct partls_ctx {
     // gram
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
-        wdev, partial, flag, yhatD, gD, nodePat, nodeFree, nodeZero, nodeSol, nodeObj;
+        wdev, partial, flag, yhatD, gD, nodePat, nodeFree, nodeZero, nodeSol, nodeObj, predX, predY;
     std::vector<double> hG, hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
     int n = 0, kbits = 0, T = 0;
@@ -50,8 +63,7 @@ struct partls_ctx {
     std::vector<uint64_t> mask_tab;
     bool use_reg = false;
     double tol = 0.0;
-    unsigned long long last_pivots = 0, last_small_pivots = 0;
-    int low_groups = 0;                            // groups 0..low_groups-1 live entirely in tile columns 0-1 (two-level sweep)
+    unsigned long long last_pivots = 0, last_vetoes = 0;
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
 };
 

@@ -23,18 +23,39 @@ __device__ __forceinline__ void gj_panel_load(const double *T, int ld, const int
     __syncthreads();
 }
 
-// returns the number of accepted pivots (uniform)
+// returns the number of accepted pivots (uniform).  Acceptance of an ENTERING variable k follows the leave-one-out rule of
+// sweep_blk.hip: d_k > piv_eps and d_k > piv_eps * T[j][k]^2 for every variable row j — the basis B + k must not be
+// numerically dependent at the piv_eps level in ANY of its members (an exactly dependent column next to a nearly collinear
+// pair passes the first test alone: its computed pivot carries an error of eps * |c|^2).  s_basic is kept live here: the flag of
+// an accepted pivot flips at the end of its step (the callers only record the rejections).  red: NT / 64 doubles of scratch.
 template <int NT>
-__device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double *dinv, double *uj, const int *ks, int m, int ld,
-                                                  const uint8_t *s_basic, double piv_eps, int tid)
+__device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double *dinv, double *uj, double *red, const int *ks, int m,
+                                                  int ld, uint8_t *s_basic, double piv_eps, int tid)
 {
     int accepted = 0;
     for (int s = 0; s < m; ++s) {
         const int k = ks[s];
-        if (tid < m) uj[tid] = Pn[(size_t)tid * ld + k];                 // pivot-row entries before the step
+        // entries of the pivot COLUMN s at the pivot rows (not of column j at row k: equal only in exact arithmetic — with the
+        // factor taken from column s the panel receives exactly the symmetric rank-1 term z_s z_s'/d_s of the fused update;
+        // mixing the two loses the solution on ill-conditioned data, see sweep_blk.hip)
+        if (tid < m) uj[tid] = Pn[(size_t)s * ld + ks[tid]];
         __syncthreads();
         const double d = uj[s];
-        const bool ok = s_basic[k] || (d > piv_eps);                     // dependent column: rejected for the current basis
+        const bool bas = s_basic[k] != 0;
+        bool ok = bas || (d > piv_eps);
+        if (ok && !bas) {                                                // uniform
+            double c2 = 0.0;
+            for (int i = tid; i < ld - 1; i += NT)                       // every variable row (nonbasic rows satisfy T_ik^2 <= d_k)
+                if (i != k) { const double z = Pn[(size_t)s * ld + i]; c2 = fmax(c2, z * z); }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c2 = fmax(c2, __shfl_xor(c2, off));
+            if ((tid & 63) == 0) red[tid >> 6] = c2;
+            __syncthreads();
+            double cmax2 = 0.0;
+            for (int w = 0; w < NT / 64; ++w) cmax2 = fmax(cmax2, red[w]);
+            ok = !(cmax2 * piv_eps >= d);
+            __syncthreads();
+        }
         const double inv = ok ? 1.0 / d : 0.0, ainv = fabs(inv);
         if (ok) {
             ++accepted;
@@ -52,7 +73,9 @@ __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double
         }
         if (tid == 0) dinv[s] = inv;
         __syncthreads();
+        if (ok && tid == 0) s_basic[k] ^= 1;                             // everybody has read the old flag; next read is behind a barrier
     }
+    __syncthreads();
     return accepted;
 }
 
@@ -69,7 +92,7 @@ __device__ __forceinline__ void gj_apply(double *T, int ld, int row0, int row1, 
         double *row = T + (size_t)i * ld;
         double fi[GJ_MB];
 #pragma unroll
-        for (int s = 0; s < GJ_MB; ++s) fi[s] = (s < m) ? -Zn[(size_t)s * ld + i] * dinv[s] : 0.0;     // 0 for rejected pivots
+        for (int s = 0; s < GJ_MB; ++s) fi[s] = (s < m && dinv[s] != 0.0) ? -Zn[(size_t)s * ld + i] * dinv[s] : 0.0;   // rejected pivot: Zn[s] was never written
         for (int c0 = lane; c0 < ld; c0 += 64 * U) {
             double acc[U];
 #pragma unroll
@@ -79,7 +102,7 @@ __device__ __forceinline__ void gj_apply(double *T, int ld, int row0, int row1, 
             }
 #pragma unroll
             for (int s = 0; s < GJ_MB; ++s) {
-                if (s < m) {
+                if (s < m && dinv[s] != 0.0) {
 #pragma unroll
                     for (int u = 0; u < U; ++u) {
                         const int c = c0 + 64 * u;

@@ -151,7 +151,7 @@ __global__ void gram_reduce_kernel(const double *__restrict__ slab, int chunks, 
     G[idx] = s;
 }
 
-static void gram_plan(int64_t N, int64_t M, int *ldg_out, int *S_out, int *chunk_rows_out, int *np_out)
+static void gram_plan(int64_t N, int64_t M, int S_env, int cr_env, int *ldg_out, int *S_out, int *chunk_rows_out, int *np_out)
 {
     const int n_aug = (int)M + 2;
     const int ldg = ((n_aug + GT - 1) / GT) * GT;
@@ -162,29 +162,28 @@ static void gram_plan(int64_t N, int64_t M, int *ldg_out, int *S_out, int *chunk
     if (cr < GK) cr = GK;
     if (cr > 4096) cr = 4096;
     // many more workgroups than resident slots (512) so that the last partial wave of workgroups is a small tail
-    const char *se = getenv("PARTLS_GRAM_S"), *ce = getenv("PARTLS_GRAM_CR");
-    if (ce) { cr = (atoll(ce) / GK) * GK; if (cr < GK) cr = GK; }
-    int S = se ? atoi(se) : (4096 + 8 * np - 1) / (8 * np);
+    if (cr_env > 0) { cr = (cr_env / GK) * GK; if (cr < GK) cr = GK; }
+    int S = S_env > 0 ? S_env : (4096 + 8 * np - 1) / (8 * np);
     if (S < 1) S = 1;
     const int64_t nchunks = (N + cr - 1) / cr;
     while (S > 1 && (int64_t)8 * S > nchunks) --S;                 // no more slices than chunks
     *ldg_out = ldg; *S_out = S; *chunk_rows_out = (int)cr; *np_out = np;
 }
 
-size_t gram_slab_doubles(int64_t N, int64_t M, int *chunks_out, int *ldg_out)
+size_t gram_slab_doubles(int64_t N, int64_t M, int gram_S, int gram_cr, int *chunks_out, int *ldg_out)
 {
     int ldg, S, cr, np;
-    gram_plan(N, M, &ldg, &S, &cr, &np);
+    gram_plan(N, M, gram_S, gram_cr, &ldg, &S, &cr, &np);
     *chunks_out = 8 * S;                                            // number of partial slabs
     *ldg_out = ldg;
     return (size_t)8 * S * ldg * ldg;
 }
 
 hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, double *slab, int chunks,
-                       int ldg, double *G, hipStream_t s)
+                       int ldg, int gram_S, int gram_cr, double *G, hipStream_t s)
 {
     int ldg2, S, cr, np;
-    gram_plan(N, M, &ldg2, &S, &cr, &np);
+    gram_plan(N, M, gram_S, gram_cr, &ldg2, &S, &cr, &np);
     hipLaunchKernelGGL(gram_kernel, dim3(8 * S * np), dim3(256), 0, s, X, N, (int)M, ldX, y, slab, ldg, cr, S, np);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -167,7 +167,7 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         const double o2 = gram_objective2(c, w);
         oldopt = optval;
         optval = std::sqrt(o2 > 0.0 ? o2 : 0.0);
-        if (getenv("PARTLS_ALT_TRACE")) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms, rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
+        if (c->knobs.alt_trace) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms, rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
         ++i;
     }
     w_from();

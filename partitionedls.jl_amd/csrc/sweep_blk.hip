@@ -1,22 +1,218 @@
-// sweep_blk.hip — production sign-pattern sweep, BLOCKED principal pivots on a register-resident tableau.
+// sweep_blk.hip — production sign-pattern sweep, BLOCKED principal pivots on a register-resident tableau (n <= 272).
 //
-// Replaces the loop body of fit(Opt), Opt.jl:87-90, for every pattern of a Gray-code chain (same mathematics and the
-// same per-pattern decisions as sweep_generic.hip / sweep_reg.hip).  What is new relative to sweep_reg.hip:
-// the violators of one KKT scan are exchanged one 16x16 TILE COLUMN at a time as a block pivot
-//     T'_RR = T_RR - sum_s z_s z_s' / d_s          (z_s = pivot column as of its own step, d_s its pivot)
-// so that the expensive part — the update of the register tableau — is ONE fused rank-m pass of uninterrupted FMAs, and
-// the per-pivot overheads of the rank-1 kernel (column gather under a scalar if-chain, barrier, LDS round trip, fix-up
-// if-chain) are paid once per tile instead of once per pivot:
-//   1. gather   : every thread writes its slots of tile column kappa to an LDS panel P[16 cols][rows] (+ rhs row);
-//   2. panel    : thread t owns ROW t of the panel in registers (<= 16 pivot columns); m sequential Gauss–Jordan steps,
-//                 each exchanging only the m pivot-row entries through LDS (one barrier per step); z_s and 1/d_s recorded;
+// Replaces the loop body of fit(Opt), Opt.jl:87-90 (indextobeta + bmatrix + nonneg_lsq + objective), for every pattern of a
+// Gray-code chain, and serves the node solves of Alt (Alt.jl:80-90) and BnB (BnB.jl:69-92); same mathematics and the same
+// per-pattern decisions as sweep_generic.hip.
+//
+// Data layout (one workgroup = 512 threads = 8 waves = 2 waves/SIMD on one CU, one tableau, one chain):
+//   * variables are padded to 16*T; the symmetric tableau is cut into 16x16 tiles (rho, gamma), rho <= gamma only;
+//   * thread (a, b) = (t & 15, (t >> 4) & 15) owns element (16 rho + a, 16 gamma + b) of EVERY stored tile — a tile-cyclic
+//     layout, so a pivot is an outer-product update in registers with static register indices only;
+//   * v_fma_f64 can address only the 256 architectural VGPRs, so the T(T+1)/2 tile slots (153 at n = 257) are split
+//     between the two halves of the workgroup by tile COLUMN (threads 0..255: gamma < G, threads 256..511: gamma >= G);
+//   * rhs column q: thread v owns q_v (v < n); the objective (corner) is replicated; KKT scan = one ballot per wave.
+// The violators of one KKT scan are exchanged one TILE COLUMN at a time as a block pivot of m <= 8 variables
+//     T'_RR = T_RR - sum_s z_s z_s' / d_s          (z_s = pivot column as of its own step, d_s its pivot):
+//   1. gather   : the pivot columns go from registers to an LDS panel P[m cols][rows] (+ rhs row), compacted;
+//   2. panel    : thread t owns ROW t of the panel in registers (<= 8 pivot columns); m sequential Gauss–Jordan steps, each
+//                 exchanging only the m pivot-row entries of the CURRENT pivot column and 1/d through LDS (one barrier per
+//                 step); z_s and 1/d_s are recorded for the update;
 //   3. update   : all 512 threads: S(rho,gamma) -= x_s[rho] * y_s[gamma] for s = 1..m (x resident, y streamed from LDS);
 //   4. scatter  : rows/columns of the pivoted variables are overwritten from the final panel (one if-chain per tile).
-// Layout of the register tableau, thread grid, half split and LDS image are those of sweep_reg.hip.
-#include "blk_common.h"
+//
+// Dependent columns.  An entering variable k is refused (Lawson–Hanson's rejection; re-examined after any exchange) when the
+// basis B + k would be numerically dependent at the 1e-11 level on the unit-diagonal scale: with c_j = T[j][k] the regression
+// coefficients of column k on the basic columns, the leave-one-out pivot of EVERY member of B + k must stay above piv_eps —
+//     d_k > piv_eps                      (k itself:  relative residual norm of x_k after regression on B)
+//     d_k > piv_eps * c_j^2  (j in B)    (1 / d_j(B + k) = 1 / d_j(B) + c_j^2 / d_k)
+// The second line is what a Gram-based method needs on top of the textbook rule: the computed d_k carries an error of
+// eps * (1 + |c|)^2, so with large coefficients (an exactly dependent column next to a nearly collinear pair) a true zero
+// comes out at 1e-11..1e-10 and the fixed threshold alone accepts it (round-1 fuzz blocks 9 and 24).  The panel is computed
+// optimistically; a thread that sees the second condition violated in its own row reports the step, the block is abandoned
+// before the register tableau is touched, the offender is marked rejected and the rest of the block is redone.
+// The test needs no basis bookkeeping: for a NONBASIC row j the Schur complement is positive semidefinite, T_jk^2 <= T_jj T_kk
+// <= d_k, so d_k > piv_eps * T_jk^2 holds with a margin of 1e11 and every row can simply test its own entry; a leaving pivot
+// has 1/d < 0 and a rejected one 1/d = 0, which fail the test by sign.  Only the rhs row (no variable) must not report.
+#include "common.h"
+#include <type_traits>
 
 namespace partls {
 namespace blk {
+
+static constexpr int THREADS = 512;
+static constexpr int MAXT = 17;                 // n <= 272
+#ifndef PARTLS_UPD_UNROLL
+#define PARTLS_UPD_UNROLL 1
+#endif
+static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks)
+static constexpr int NO_VETO = 99;
+
+constexpr int nslots(int T) { return T * (T + 1) / 2; }
+constexpr int tri(int g) { return g * (g + 1) / 2; }
+constexpr int split(int T)
+{
+    int best = 1, bestmax = 1 << 30;
+    for (int g = 1; g < T; ++g) {
+        int a = tri(g), b = nslots(T) - tri(g);
+        int m = a > b ? a : b;
+        if (m < bestmax) { bestmax = m; best = g; }
+    }
+    return T == 1 ? 1 : best;
+}
+constexpr int rstride(int T) { return (T % 2) ? T : T + 1; }      // odd row stride: 16 lanes x 8 B hit 32 distinct banks
+constexpr int colw(int T) { return 513; }                          // panel column: one slot per thread (16*RS rows + rhs + dummies), odd
+// LDS doubles: P[2][MB][COLW], Z[MB][COLW], U[2][MB+64], Dinv[MB+64] (64 per-lane dummy slots each); then 32 x u64 mask
+// words and 2 veto slots
+constexpr int lds_doubles(int T) { return 3 * MB * colw(T) + 3 * (MB + 64); }
+constexpr int lds_words(int T) { return 32 + 2 + 2 + 16 * T; }      // masks, veto slots, running best (obj^2, pattern), group masks
+
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return y;
+}
+__device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
+__device__ __forceinline__ double readlane_f64(double v, int lane)      // lane: wave-uniform
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Diagnostic build only (-DPARTLS_STAMPS): per-phase cycle shares of workgroup 0 / thread 0, written to p.scratch[0..23]
+// (a buffer no other code of the kernel reads).  Never quote this build's run time (cdna_hip_programming.md §7).
+#ifdef PARTLS_STAMPS
+#define STAMP_DECL unsigned long long st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(ph) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _n = __builtin_amdgcn_s_memtime(); \
+                       st_acc[ph] += _n - st_t; st_t = _n; __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef PARTLS_STAMP_TID
+#define PARTLS_STAMP_TID 0
+#endif
+#define STAMP_FLUSH do { if (tid == PARTLS_STAMP_TID && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 24; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(ph) do { } while (0)
+#define STAMP_FLUSH do { } while (0)
+#endif
+
+template <int T, int H>
+struct Half {
+    static constexpr int G = split(T);
+    static constexpr int GLO = H ? G : 0;
+    static constexpr int GHI = H ? T : G;
+    static constexpr int OFF = H ? tri(G) : 0;
+    static constexpr int CNT = (H ? nslots(T) - tri(G) : tri(G)) > 0 ? (H ? nslots(T) - tri(G) : tri(G)) : 1;
+    static constexpr int XN = GHI;
+    static constexpr int RS = rstride(T);
+    static constexpr int CW = colw(T);
+    __device__ static constexpr int idx(int rho, int gam) { return tri(gam) + rho - OFF; }
+};
+
+// ---- tile-column gather ------------------------------------------------------------------------------------------------
+// Element (16 rho + a, 16 KAPPA + b) belongs to column b of the tile, row position a*RS + rho.  Only the pivot columns are
+// gathered, COMPACTED: the j-th pivot of the block (ascending local index) becomes panel column j = popc(pm below it).
+template <int T, int H, int KAPPA, class SA>
+__device__ __forceinline__ void gather_tile(const SA &S, double *P, int a, int b, unsigned pm)
+{
+    using L = Half<T, H>;
+    if constexpr (KAPPA >= L::GLO && KAPPA < L::GHI) {
+        if ((pm >> b) & 1u) {
+            double *col = P + __builtin_popcount(pm & ((1u << b) - 1u)) * L::CW + a * L::RS;
+#pragma unroll
+            for (int rho = 0; rho <= KAPPA; ++rho) col[rho] = S[L::idx(rho, KAPPA)];
+        }
+    }
+    // row KAPPA of the stored triangle = column (16 KAPPA + a) by symmetry, row position b*RS + gamma
+    if ((pm >> a) & 1u) {
+        double *col = P + __builtin_popcount(pm & ((1u << a) - 1u)) * L::CW + b * L::RS;
+#pragma unroll
+        for (int gam = (KAPPA + 1 > L::GLO ? KAPPA + 1 : L::GLO); gam < L::GHI; ++gam) col[gam] = S[L::idx(KAPPA, gam)];
+    }
+}
+
+template <int T, int H, int KAPPA, class SA>
+__device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int b, unsigned pm)
+{
+    using L = Half<T, H>;
+    if constexpr (KAPPA >= L::GLO && KAPPA < L::GHI) {
+        if ((pm >> b) & 1u) {
+            const double *col = P + __builtin_popcount(pm & ((1u << b) - 1u)) * L::CW + a * L::RS;
+#pragma unroll
+            for (int rho = 0; rho <= KAPPA; ++rho) S[L::idx(rho, KAPPA)] = col[rho];
+        }
+    }
+    if ((pm >> a) & 1u) {
+        const double *col = P + __builtin_popcount(pm & ((1u << a) - 1u)) * L::CW + b * L::RS;
+#pragma unroll
+        for (int gam = (KAPPA > L::GLO ? KAPPA : L::GLO); gam < L::GHI; ++gam) S[L::idx(KAPPA, gam)] = col[gam];
+    }
+}
+
+// ---- panel elimination for a block of exactly M pivots (M = 1..MB); straight-line code, no guards ------------------------
+// Thread t owns row position `prow` (= t for the real positions) of the M (compacted) pivot columns in registers pv[0..M);
+// threads beyond the rhs row work on dummy positions: computed, stored, never read.  Step s: the pivot-row threads publish
+// their entry of column s through U, the thread that IS pivot row s also publishes 1/d (0 for a dependent column, Lawson–
+// Hanson's rejection) — both as unconditional stores, non-owners hit a dummy slot — one barrier, one batch of broadcast
+// reads, then every thread updates its own row with  T_ij -= T_is T_sj / d,  T_is = T_is / |d|,  T_ss = -1/d.
+// NUMERICS: the factor T_sj is taken from the pivot COLUMN s (its entry at pivot row j, u[j]) — never from column j at pivot
+// row s, which is the same number only in exact arithmetic.  With u from column s the panel receives exactly the symmetric
+// rank-1 term z_s z_s' / d_s that the register tableau receives in the update; mixing the two breaks that consistency and
+// loses the solution on ill-conditioned data (pivots ~1e-8: measured, tools/tableau_emul.py --block).
+// `my_basic`: this thread is a pivot row and its variable is basic (leaves).
+// Returns the first step whose entering pivot this thread's row vetoes under the leave-one-out rule (file header), M if none.
+template <int M, int CW>
+__device__ __forceinline__ int panel_block(double *P, double *Z, double *U, double *Dinv, int myj, bool my_basic,
+                                           double piv_eps, int tid, int prow, bool idle_wave)
+{
+    // A wave whose 64 row positions all lie beyond the rhs row owns no panel row.  Two waves share a SIMD's issue slots, so
+    // such a wave only keeps the barrier count instead of competing with a real wave.
+    if (idle_wave) {
+#pragma unroll
+        for (int s = 0; s < M; ++s) __syncthreads();
+        return M;
+    }
+    constexpr int US = MB + 64;                             // U row stride; slots MB.. are per-lane dummies (no same-address stores)
+    const int dummy = MB + (tid & 63);
+    double pv[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) pv[j] = P[j * CW + prow];
+    const int uslot = myj >= 0 ? myj : dummy;
+    int veto = M;
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        Z[s * CW + prow] = pv[s];
+        U[(s & 1) * US + uslot] = pv[s];
+        {
+            const double d = pv[s];
+            const double r = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
+            Dinv[myj == s ? s : dummy] = r;
+        }
+        __syncthreads();
+        const double inv = Dinv[s], ainv = fabs(inv);
+        double u[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
+        const bool ok = inv != 0.0, isrow = (myj == s);
+        // leave-one-out veto: T_js^2 >= d / piv_eps  (inv = 1/d; negative for a leaving pivot, 0 for a rejected one)
+        if ((pv[s] * pv[s]) * (inv * piv_eps) >= 1.0) veto = veto < s ? veto : s;
+        const double fz = pv[s] * inv;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            if (j == s) continue;
+            const double upd = isrow ? u[j] * ainv : fma(-fz, u[j], pv[j]);
+            pv[j] = ok ? upd : pv[j];
+        }
+        pv[s] = ok ? (isrow ? -inv : pv[s] * ainv) : pv[s];
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) P[j * CW + prow] = pv[j];
+    return veto;
+}
+
+#define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
 
 template <int T, int H>
 __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
@@ -32,24 +228,29 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
     double *U = Z + MB * CW;                              // [2][MB+64]
     double *Dinv = U + 2 * (MB + 64);                     // [MB+64]
     unsigned long long *s_inf = reinterpret_cast<unsigned long long *>(Dinv + MB + 64);  // [2][8]
-    unsigned long long *s_bas = s_inf + 16;                                            // [2][8]
+    unsigned long long *s_bas = s_inf + 16;                                              // [2][8]
+    int *s_veto = reinterpret_cast<int *>(s_bas + 16);                                   // [2] first vetoed step of a block
+    // per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
+    double *s_best = reinterpret_cast<double *>(s_bas + 18);                             // [2] running minimum: obj^2, pattern (as bits)
+    unsigned long long *s_vmask = s_bas + 20;                                            // [16 T] group mask of variable v
 
-    for (int i = tid; i < lds_doubles(T) + 32; i += THREADS) lds[i] = 0.0;            // padding rows are never gathered
+    for (int i = tid; i < lds_doubles(T) + lds_words(T); i += THREADS) lds[i] = 0.0;    // padding rows are never gathered
+    __syncthreads();
+    if (tid < 2) s_veto[tid] = NO_VETO;
+    if (tid == 0) { s_best[0] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[1] = -1; }
+    if (tid < 16 * T) s_vmask[tid] = tid < p.n ? p.mask[tid] : 0ULL;
     __syncthreads();
 
     double S[L::CNT];
     double q = 0.0, corner = 0.0;
     const bool has_var = tid < n;
-    const uint64_t vmask = has_var ? p.mask[tid] : 0ULL;
     bool basic = false, blocked = false;
     const int mypos = (tid & 15) * RS + (tid >> 4);       // panel row position of variable `tid` (tid < 16 T)
     // panel phase: this thread owns row position `tid`, i.e. variable 16*rowrho + rowc (valid when rowc < 16)
     const int rowc = tid / RS, rowrho = tid - rowc * RS;
     const bool idle_wave = __builtin_amdgcn_readfirstlane((tid & ~63) > RHSPOS ? 1 : 0) != 0;   // no panel row in this wave
 
-    double best_obj = __builtin_inf();
-    long long best_pat = -1;
-    unsigned long long npiv = 0, nunconv = 0;
+    unsigned long long npiv = 0, nunconv = 0, nveto = 0;
     unsigned bc = 0, sc = 0;                              // block / scan counters (double-buffer parity)
 
     const int64_t total = p.g_end - p.g_begin;
@@ -69,6 +270,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
 
         for (int64_t g = g0; g < g1; ++g) {
             uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            const uint64_t vmask = s_vmask[tid < 16 * T ? tid : 0] & (has_var ? ~0ULL : 0ULL);
             bool isfree = false;
             int f;
             if (p.node_pat) {                                       // node mode: chain index = node index
@@ -140,10 +342,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         const unsigned pm = pmall & ~rest;
                         pmall = rest;
                         const int m = __builtin_popcount(pm);
-                        double *P = Pbase + (bc & 1) * MB * CW;
+                        const int bpar = bc & 1;
+                        double *P = Pbase + bpar * MB * CW;
                         ++bc;
                         // ---- 1. gather the pivot columns (compacted) into the LDS panel ------------------------------------
-#define PARTLS_G(i) if constexpr (i < T) { if (__builtin_expect(kappa == i, 0)) gather_tile<T, H, i, CW>(S, P, a, b, pm); }
+#define PARTLS_G(i) if constexpr (i < T) { if (__builtin_expect(kappa == i, 0)) gather_tile<T, H, i>(S, P, a, b, pm); }
                         PARTLS_CASES(PARTLS_G)                 // flat chain of independent ifs: the only form the register allocator keeps spill-free
 #undef PARTLS_G
                         if (tid < 16 * T && (tid >> 4) == kappa && ((pm >> (tid & 15)) & 1u))
@@ -158,25 +361,47 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         STAMP(8);
                         __syncthreads();
                         STAMP(1);
+                        if (tid == 0) s_veto[bpar ^ 1] = NO_VETO;              // the other slot: last read before this barrier
                         // ---- 2. panel elimination -----------------------------------------------------------------------
-                        bool blk_ok = false;
-                        switch (m) {
-                            case 1: blk_ok = panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            case 2: blk_ok = panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            case 3: blk_ok = panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            case 4: blk_ok = panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            case 5: blk_ok = panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            case 6: blk_ok = panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            case 7: blk_ok = panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                            default: blk_ok = panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                        {
+                            int veto;
+                            switch (m) {
+                                case 1: veto = panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                case 2: veto = panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                case 3: veto = panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                case 4: veto = panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                case 5: veto = panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                case 6: veto = panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                case 7: veto = panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                                default: veto = panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+                            }
+                            if (veto < m && tid != RHSPOS) atomicMin(&s_veto[bpar], veto);     // the rhs row is no variable
                         }
                         STAMP(11);
                         __syncthreads();
                         STAMP(2);
+                        // leave-one-out veto at step vs: nothing of this block has touched the register tableau yet.  The offender
+                        // is rejected for the current basis and the other pivots of the block are redone; the rest of the block body
+                        // runs with ZERO pivots (no extra control-flow edge in the block loop: the allocator keeps the tableau put)
+                        const int vs = __builtin_amdgcn_readfirstlane(s_veto[bpar]);
+                        unsigned pmx = pm;
+                        int mx = m;
+                        if (__builtin_expect(vs < m, 0)) {
+                            unsigned r = pm;
+                            for (int i = 0; i < vs; ++i) r &= r - 1;
+                            const unsigned vbit = r & (0u - r);
+                            blocked = blocked || (tid == 16 * kappa + __builtin_ctz(vbit));
+                            pmall |= pm & ~vbit;
+                            pmx = 0;
+                            mx = 0;
+                            ++nveto;
+                        }
                         // ---- 3. fused rank-m update of the register tableau ------------------------------------------------
+                        bool blk_ok = false;
 #pragma unroll PARTLS_UPD_UNROLL
-                        for (int s = 0; s < m; ++s) {
+                        for (int s = 0; s < mx; ++s) {
                             const double inv = Dinv[s];
+                            blk_ok = blk_ok || (inv != 0.0);
                             const double *Zs = Z + s * CW;
                             double x[L::XN];
 #pragma unroll
@@ -194,17 +419,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
                         }
                         STAMP(3);
                         // ---- 4. rows / columns of the pivoted variables come from the final panel ----------------------------
-#define PARTLS_F(i) if constexpr (i < T) { if (__builtin_expect(kappa == i, 0)) scatter_tile<T, H, i, CW>(S, P, a, b, pm); }
+#define PARTLS_F(i) if constexpr (i < T) { if (__builtin_expect(kappa == i, 0)) scatter_tile<T, H, i>(S, P, a, b, pmx); }
                         PARTLS_CASES(PARTLS_F)
 #undef PARTLS_F
-                        if (tid < 16 * T && (tid >> 4) == kappa && ((pm >> (tid & 15)) & 1u)) {
-                            const int j = __builtin_popcount(pm & ((1u << (tid & 15)) - 1u));
+                        if (tid < 16 * T && (tid >> 4) == kappa && ((pmx >> (tid & 15)) & 1u)) {
+                            const int j = __builtin_popcount(pmx & ((1u << (tid & 15)) - 1u));
                             q = P[j * CW + RHSPOS];
                             if (Dinv[j] != 0.0) basic = !basic;
                             else blocked = true;
                         }
                         progress = progress || blk_ok;
-                        npiv += (unsigned)m;
+                        npiv += (unsigned)mx;
                         STAMP(4);
                     }
                     tiles &= tiles - 1;
@@ -214,7 +439,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
             // pattern, unless every pattern's objective is wanted
             const double obj2 = corner > 0.0 ? corner : 0.0;
             if (p.all_opt && tid == 0) p.all_opt[pat] = sqrt(obj2);
-            if (obj2 < best_obj || (obj2 == best_obj && (long long)pat < best_pat)) { best_obj = obj2; best_pat = (long long)pat; }
+            if (tid == 0) {                                          // lexicographic (objective, pattern) minimum: argmin's first-index rule
+                const double bo = s_best[0];
+                const long long bp = reinterpret_cast<long long *>(s_best)[1];
+                if (obj2 < bo || (obj2 == bo && (long long)pat < bp)) { s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat; }
+            }
         }
         if (p.node_sol) {
             if (has_var) p.node_sol[(size_t)chain * p.node_ld + tid] = basic ? q : 0.0;
@@ -223,13 +452,20 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
     }
     STAMP_FLUSH;
     if (tid == 0) {
-        p.best_obj[blockIdx.x] = sqrt(best_obj);
-        p.best_pat[blockIdx.x] = best_pat;
+        p.best_obj[blockIdx.x] = sqrt(s_best[0]);
+        p.best_pat[blockIdx.x] = reinterpret_cast<long long *>(s_best)[1];
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
+        if (p.n_vetoes && nveto) atomicAdd(p.n_vetoes, nveto);
     }
 }
 
+// Barrier invariant.  The two halves of the workgroup run DIFFERENT instantiations (sweep_body<T,0> / <T,1>) and meet at
+// workgroup barriers issued from different program counters.  That is only sound because every barrier of the body is reached
+// under wave-uniform control flow whose conditions (count, tiles, pmall, m, vs, rounds, patience, chain and pattern counters)
+// are computed from LDS words or kernel arguments that are identical for all 512 threads — never from a half's own registers —
+// so both instantiations execute the same barrier sequence: per scan 1, per block 2 + m (the m panel steps; idle waves only
+// count them).  Any edit that makes a barrier conditional on per-half or per-wave data deadlocks the CU.
 template <int T>
 __global__ __launch_bounds__(THREADS, 2) void sweep_blk_kernel(SweepParams p)
 {
@@ -239,19 +475,50 @@ __global__ __launch_bounds__(THREADS, 2) void sweep_blk_kernel(SweepParams p)
     else sweep_body<T, 1>(p, lds);
 }
 
+// Tfull ((n+1)^2) -> tile-cyclic initial state: [slot = tri(gamma) + rho][256 = a + 16 b], then q0[16 T], then the corner
+__global__ void layout_reg_kernel(const double *__restrict__ Tfull, int n, int T, double *__restrict__ out)
+{
+    const int ld = n + 1;
+    const int ns = T * (T + 1) / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tot = ns * 256 + 16 * T + 1;
+    if (idx >= tot) return;
+    if (idx < ns * 256) {
+        const int s = idx >> 8, t8 = idx & 255, a = t8 & 15, b = t8 >> 4;
+        int gam = 0;
+        while ((gam + 1) * (gam + 2) / 2 <= s) ++gam;
+        const int rho = s - gam * (gam + 1) / 2;
+        const int i = 16 * rho + a, j = 16 * gam + b;
+        out[idx] = (i < n && j < n) ? Tfull[(size_t)i * ld + j] : ((i == j) ? 1.0 : 0.0);
+    } else if (idx < ns * 256 + 16 * T) {
+        const int v = idx - ns * 256;
+        out[idx] = (v < n) ? Tfull[(size_t)v * ld + n] : 0.0;
+    } else {
+        out[idx] = Tfull[(size_t)n * ld + n];
+    }
+}
+
 }  // namespace blk
+
+bool sweep_reg_supported(int n) { return n >= 1 && n <= 16 * blk::MAXT; }
+int sweep_reg_tiles(int n) { return (n + 15) / 16; }
+size_t sweep_reg_t0_doubles(int T) { return (size_t)T * (T + 1) / 2 * 256 + 16 * (size_t)T + 8; }
+
+hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, hipStream_t s)
+{
+    const int tot = T * (T + 1) / 2 * 256 + 16 * T + 1;
+    hipLaunchKernelGGL(blk::layout_reg_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, Tfull, n, T, T0reg);
+    return hipGetLastError();
+}
 
 template <int T>
 static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
 {
-    const size_t shmem = (size_t)blk::lds_doubles(T) * sizeof(double) + 32 * sizeof(unsigned long long);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blk::sweep_blk_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    const size_t shmem = ((size_t)blk::lds_doubles(T) + blk::lds_words(T)) * sizeof(double);
+    // the attribute is per device: set it on every launch (a host-side store, no device work)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blk::sweep_blk_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(blk::sweep_blk_kernel<T>, dim3(grid), dim3(blk::THREADS), shmem, s, p);
     return hipGetLastError();
 }
@@ -259,9 +526,13 @@ static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s)
 {
     switch (T) {
+#ifdef PARTLS_ONLY_T
+        case PARTLS_ONLY_T: return launch_blk_T<PARTLS_ONLY_T>(p, grid, s);
+#else
 #define PARTLS_L(i) case i + 1: return launch_blk_T<i + 1>(p, grid, s);
         PARTLS_CASES(PARTLS_L)
 #undef PARTLS_L
+#endif
         default: return hipErrorInvalidValue;
     }
 }

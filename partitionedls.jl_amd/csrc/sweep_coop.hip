@@ -13,8 +13,8 @@
 //                barriers only; column s as of its own step is kept in Z[s][.], 1/d_s in dinv[s] (0 = rejected as dependent);
 //   3. update  : each workgroup applies the fused rank-m update T_ic -= sum_s Z_s[i] Z_s[c] / d_s to ITS rows, then overwrites
 //                the rows / columns of the pivoted variables from the final panel;
-//   4. one grid barrier.
-// So the grid synchronises once per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables).
+//   4. one grid barrier (plus one between 1 and 3: the panel copies must be complete before any owner rewrites a pivot row).
+// So the grid synchronises twice per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables).
 #include "gj_panel.h"
 #include <hip/hip_cooperative_groups.h>
 
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
     double *Zn = Pn + (size_t)mb * ld;                            // [mb][ld] column s as of its own step
     double *dinv = Zn + (size_t)mb * ld;                          // [COOP_MB] 1/d_s (0: rejected)
     double *uj = dinv + COOP_MB;                                  // [COOP_MB] pivot-row entries of the current step
-    uint8_t *s_basic = reinterpret_cast<uint8_t *>(uj + COOP_MB);
+    double *red = uj + COOP_MB;                                   // [COOP_THREADS / 64] reduction scratch
+    uint8_t *s_basic = reinterpret_cast<uint8_t *>(red + COOP_THREADS / 64);
     uint8_t *s_blocked = s_basic + n;
     __shared__ unsigned long long s_inf[COOP_MAXWORDS];
     __shared__ int s_viol[COOP_MAXWORDS * 64];
@@ -112,11 +113,14 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             const int *ks = s_viol + b0;
             // ---- 1. panel, 2. redundant elimination (block-local barriers only), 3. fused update of the owned rows ------------
             gj_panel_load<COOP_THREADS>(T, ld, ks, m, Pn, tid);
-            gj_panel_eliminate<COOP_THREADS>(Pn, Zn, dinv, uj, ks, m, ld, s_basic, p.piv_eps, tid);
+            // every workgroup has its copy of the pivot rows (and has finished the KKT scan of the rhs row) before any owner
+            // rewrites them: without this barrier a fast workgroup's update races with a slow one's panel load
+            grid.sync();
+            gj_panel_eliminate<COOP_THREADS>(Pn, Zn, dinv, uj, red, ks, m, ld, s_basic, p.piv_eps, tid);
             gj_apply<COOP_THREADS>(T, ld, row0, row1, Pn, Zn, dinv, ks, m, tid);
             if (tid == 0) {
                 for (int j = 0; j < m; ++j) {
-                    if (dinv[j] != 0.0) s_basic[ks[j]] ^= 1; else s_blocked[ks[j]] = 1;
+                    if (dinv[j] == 0.0) s_blocked[ks[j]] = 1;                // accepted pivots flipped s_basic in the panel
                 }
             }
             for (int j = 0; j < m; ++j) if (dinv[j] != 0.0) { progress = true; ++npiv; }
@@ -143,7 +147,7 @@ hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s)
     const int ld = p.n + 1;
     // pivots per block: two [mb][ld] LDS images within ~136 KB
     int mb = gj_block_size(ld, (size_t)136 * 1024);
-    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + 2 * COOP_MB * sizeof(double) + 2 * (size_t)p.n + 16;
+    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + (2 * COOP_MB + COOP_THREADS / 64) * sizeof(double) + 2 * (size_t)p.n + 16;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_coop_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;

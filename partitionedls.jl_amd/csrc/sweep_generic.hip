@@ -15,7 +15,7 @@
 // This kernel is the fully general form: full (n+1)^2 tableau per workgroup in global scratch.  With 256 concurrent
 // tableaus of 2 MB (n = 513) the passes over the tableau are HBM-bound, so the violators of a scan are exchanged in BLOCKS of up
 // to 16 pivots (gj_panel.h: panel of the pivot columns eliminated in LDS, then ONE fused rank-m pass over the tableau) instead
-// of one full pass per pivot.  The register-resident production kernels are sweep_blk.hip / sweep_reg.hip; all share
+// of one full pass per pivot.  The register-resident production kernel is sweep_blk.hip; all share
 // SweepParams and agree in their decisions up to rounding.
 #include "gj_panel.h"
 
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
     double *Zn = Pn + (size_t)mb * ld;                            // [mb][ld] column s as of its own step
     double *dinv = Zn + (size_t)mb * ld;                          // [GJ_MB] 1/d_s (0: rejected)
     double *uj = dinv + GJ_MB;                                    // [GJ_MB] pivot-row entries of the current step
-    uint8_t *s_basic = reinterpret_cast<uint8_t *>(uj + GJ_MB);   // n bytes
+    double *red = uj + GJ_MB;                                     // [GEN_THREADS / 64] reduction scratch
+    uint8_t *s_basic = reinterpret_cast<uint8_t *>(red + GEN_THREADS / 64);   // n bytes
     uint8_t *s_blocked = s_basic + n;                             // n bytes
     __shared__ unsigned long long s_inf[GEN_MAXWORDS];
     __shared__ int s_viol[GEN_MAXWORDS * 64];
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                     const int m = (nv - b0 < mb) ? nv - b0 : mb;
                     const int *ks = s_viol + b0;
                     gj_panel_load<GEN_THREADS>(T, ld, ks, m, Pn, tid);
-                    const int acc = gj_panel_eliminate<GEN_THREADS>(Pn, Zn, dinv, uj, ks, m, ld, s_basic, p.piv_eps, tid);
+                    const int acc = gj_panel_eliminate<GEN_THREADS>(Pn, Zn, dinv, uj, red, ks, m, ld, s_basic, p.piv_eps, tid);
                     gj_apply<GEN_THREADS>(T, ld, 0, ld, Pn, Zn, dinv, ks, m, tid);
                     if (tid == 0) {
                         for (int j = 0; j < m; ++j) {
-                            if (dinv[j] != 0.0) s_basic[ks[j]] ^= 1; else s_blocked[ks[j]] = 1;
+                            if (dinv[j] == 0.0) s_blocked[ks[j]] = 1;        // accepted pivots flipped s_basic in the panel
                         }
                     }
                     if (acc) { npiv += (unsigned)acc; progress = true; }
@@ -154,7 +155,7 @@ hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s)
 {
     const int ld = p.n + 1;
     int mb = gj_block_size(ld, (size_t)136 * 1024);
-    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + 2 * GJ_MB * sizeof(double) + 2 * (size_t)p.n + 16;
+    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + (2 * GJ_MB + GEN_THREADS / 64) * sizeof(double) + 2 * (size_t)p.n + 16;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_generic_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
