@@ -61,11 +61,6 @@ constexpr int split(int T)
 }
 constexpr int rstride(int T) { return (T % 2) ? T : T + 1; }      // odd row stride: 16 lanes x 8 B hit 32 distinct banks
 constexpr int colw(int T) { return 513; }                          // panel column: one slot per thread (16*RS rows + rhs + dummies), odd
-// LDS doubles: P[2][MB][COLW], Z[MB][COLW], U[2][MB+64], Dinv[MB+64] (64 per-lane dummy slots each); then 32 x u64 mask
-// words and 2 veto slots
-constexpr int lds_doubles(int T) { return 3 * MB * colw(T) + 3 * (MB + 64); }
-constexpr int lds_words(int T) { return 32 + 2 + 2 + 16 * T; }      // masks, veto slots, running best (obj^2, pattern), group masks
-
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double y = __builtin_amdgcn_rcp(d);
@@ -97,6 +92,21 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane:
 #define STAMP(ph) do { } while (0)
 #define STAMP_FLUSH do { } while (0)
 #endif
+
+// LDS image, statically allocated at namespace scope (one copy per kernel, shared by the two half instantiations): every
+// address is a link-time constant that folds into the ds_* immediates — with a dynamic base the compiler kept ~20 slot
+// addresses in SGPRs and spilled them to VGPR lanes inside the panel steps.  ~100 KB of the CU's 160 KB.
+static constexpr int CWMAX = colw(MAXT);
+__shared__ double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
+__shared__ double Z[MB * CWMAX];                      // [MB][CW] pivot column s as of its own step
+__shared__ double U[2 * (MB + 64)];                   // [2][MB+64] pivot-row entries of the current column (+ per-lane dummies)
+__shared__ double Dinv[MB + 64];                      // 1/d_s
+__shared__ unsigned long long s_inf[16];              // [2][8] violator mask of the scan
+__shared__ unsigned long long s_bas[16];              // [2][8] basis mask of the scan
+__shared__ int s_veto[2];                             // first vetoed step of a block (by block parity)
+// per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
+__shared__ double s_best[2];                          // running minimum: obj^2, pattern (as bits)
+__shared__ unsigned long long s_vmask[16 * MAXT];     // group mask of variable v
 
 template <int T, int H>
 struct Half {
@@ -185,27 +195,28 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
     for (int s = 0; s < M; ++s) {
         Z[s * CW + prow] = pv[s];
         U[(s & 1) * US + uslot] = pv[s];
-        {
+        if (myj == s) {                                     // the one pivot-row thread (its wave only: the others branch over)
             const double d = pv[s];
-            const double r = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
-            Dinv[myj == s ? s : dummy] = r;
+            Dinv[s] = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
         }
         __syncthreads();
-        const double inv = Dinv[s], ainv = fabs(inv);
+        const double inv = Dinv[s];
         double u[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
-        const bool ok = inv != 0.0, isrow = (myj == s);
         // leave-one-out veto: T_js^2 >= d / piv_eps  (inv = 1/d; negative for a leaving pivot, 0 for a rejected one)
         if ((pv[s] * pv[s]) * (inv * piv_eps) >= 1.0) veto = veto < s ? veto : s;
-        const double fz = pv[s] * inv;
+        // inv is the same in every lane: a scalar branch skips a rejected pivot (1/d = 0: exponent field 0)
+        if (__builtin_amdgcn_readfirstlane(__double2hiint(inv)) & 0x7ff00000) {
+            const double ainv = fabs(inv), fz = -pv[s] * inv;
+            if (myj == s) {                                 // pivot row: T_sj / |d| from the pivot COLUMN's entries, T_ss = -1/d
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            if (j == s) continue;
-            const double upd = isrow ? u[j] * ainv : fma(-fz, u[j], pv[j]);
-            pv[j] = ok ? upd : pv[j];
+                for (int j = 0; j < M; ++j) pv[j] = (j == s) ? -inv : u[j] * ainv;
+            } else {
+#pragma unroll
+                for (int j = 0; j < M; ++j) pv[j] = (j == s) ? pv[s] * ainv : fma(fz, u[j], pv[j]);
+            }
         }
-        pv[s] = ok ? (isrow ? -inv : pv[s] * ainv) : pv[s];
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) P[j * CW + prow] = pv[j];
@@ -215,7 +226,7 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
 #define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
 
 template <int T, int H>
-__device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
+__device__ __forceinline__ void sweep_body(const SweepParams &p)
 {
     using L = Half<T, H>;
     constexpr int RS = L::RS, CW = L::CW, RHSPOS = 16 * RS;
@@ -223,19 +234,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
 
-    double *Pbase = lds;                                  // [2][MB][CW]
-    double *Z = lds + 2 * MB * CW;                        // [MB][CW]
-    double *U = Z + MB * CW;                              // [2][MB+64]
-    double *Dinv = U + 2 * (MB + 64);                     // [MB+64]
-    unsigned long long *s_inf = reinterpret_cast<unsigned long long *>(Dinv + MB + 64);  // [2][8]
-    unsigned long long *s_bas = s_inf + 16;                                              // [2][8]
-    int *s_veto = reinterpret_cast<int *>(s_bas + 16);                                   // [2] first vetoed step of a block
-    // per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
-    double *s_best = reinterpret_cast<double *>(s_bas + 18);                             // [2] running minimum: obj^2, pattern (as bits)
-    unsigned long long *s_vmask = s_bas + 20;                                            // [16 T] group mask of variable v
-
-    for (int i = tid; i < lds_doubles(T) + lds_words(T); i += THREADS) lds[i] = 0.0;    // padding rows are never gathered
-    __syncthreads();
+    for (int i = tid; i < 2 * MB * CW; i += THREADS) Pbase[i] = 0.0;                   // padding rows are never gathered
+    for (int i = tid; i < MB * CW; i += THREADS) Z[i] = 0.0;
+    if (tid < 2 * (MB + 64)) U[tid] = 0.0;
+    if (tid < MB + 64) Dinv[tid] = 0.0;
+    if (tid < 16) { s_inf[tid] = 0; s_bas[tid] = 0; }
     if (tid < 2) s_veto[tid] = NO_VETO;
     if (tid == 0) { s_best[0] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[1] = -1; }
     if (tid < 16 * T) s_vmask[tid] = tid < p.n ? p.mask[tid] : 0ULL;
@@ -469,10 +472,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p, double *lds)
 template <int T>
 __global__ __launch_bounds__(THREADS, 2) void sweep_blk_kernel(SweepParams p)
 {
-    extern __shared__ double lds[];
     const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    if (half == 0) sweep_body<T, 0>(p, lds);
-    else sweep_body<T, 1>(p, lds);
+    if (half == 0) sweep_body<T, 0>(p);
+    else sweep_body<T, 1>(p);
 }
 
 // Tfull ((n+1)^2) -> tile-cyclic initial state: [slot = tri(gamma) + rho][256 = a + 16 b], then q0[16 T], then the corner
@@ -514,12 +516,7 @@ hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, h
 template <int T>
 static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
 {
-    const size_t shmem = ((size_t)blk::lds_doubles(T) + blk::lds_words(T)) * sizeof(double);
-    // the attribute is per device: set it on every launch (a host-side store, no device work)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blk::sweep_blk_kernel<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(blk::sweep_blk_kernel<T>, dim3(grid), dim3(blk::THREADS), shmem, s, p);
+    hipLaunchKernelGGL(blk::sweep_blk_kernel<T>, dim3(grid), dim3(blk::THREADS), 0, s, p);   // ~100 KB of static LDS
     return hipGetLastError();
 }
 
