@@ -103,6 +103,7 @@ __shared__ double U[2 * (MB + 64)];                   // [2][MB+64] pivot-row en
 __shared__ double Dinv[MB + 64];                      // 1/d_s
 __shared__ unsigned long long s_inf[16];              // [2][8] violator mask of the scan
 __shared__ unsigned long long s_bas[16];              // [2][8] basis mask of the scan
+__shared__ unsigned s_sum[16];                        // [2][8] per-wave summary of s_inf: count | tile bits << 8
 __shared__ int s_veto[2];                             // first vetoed step of a block (by block parity)
 // per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
 __shared__ double s_best[2];                          // running minimum: obj^2, pattern (as bits)
@@ -225,11 +226,13 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
 
 #define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16)
 
-template <int T, int H>
+// NODE: node mode (Alt alpha-steps, BnB bounds: one subproblem per chain, free / zero groups) is a separate instantiation, so
+// that the chain-mode sweep carries neither the node pointers nor the per-thread `free` flag through its loops.
+template <int T, int H, bool NODE>
 __device__ __forceinline__ void sweep_body(const SweepParams &p)
 {
     using L = Half<T, H>;
-    constexpr int RS = L::RS, CW = L::CW, RHSPOS = 16 * RS;
+    constexpr int RS = L::RS, CW = L::CW, RHSPOS = 16 * RS, NW = (T + 3) / 4;      // NW: 64-bit mask words that can be non-empty
     const int tid = threadIdx.x, t8 = tid & 255, a = t8 & 15, b = t8 >> 4, lane = tid & 63, wave = tid >> 6;
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
@@ -238,7 +241,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     for (int i = tid; i < MB * CW; i += THREADS) Z[i] = 0.0;
     if (tid < 2 * (MB + 64)) U[tid] = 0.0;
     if (tid < MB + 64) Dinv[tid] = 0.0;
-    if (tid < 16) { s_inf[tid] = 0; s_bas[tid] = 0; }
+    if (tid < 16) { s_inf[tid] = 0; s_bas[tid] = 0; s_sum[tid] = 0; }
     if (tid < 2) s_veto[tid] = NO_VETO;
     if (tid == 0) { s_best[0] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[1] = -1; }
     if (tid < 16 * T) s_vmask[tid] = tid < p.n ? p.mask[tid] : 0ULL;
@@ -253,7 +256,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     const int rowc = tid / RS, rowrho = tid - rowc * RS;
     const bool idle_wave = __builtin_amdgcn_readfirstlane((tid & ~63) > RHSPOS ? 1 : 0) != 0;   // no panel row in this wave
 
-    unsigned long long npiv = 0, nunconv = 0, nveto = 0;
+    unsigned npiv = 0, nunconv = 0, nveto = 0;            // per workgroup: far below 2^32
     unsigned bc = 0, sc = 0;                              // block / scan counters (double-buffer parity)
 
     const int64_t total = p.g_end - p.g_begin;
@@ -276,7 +279,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             const uint64_t vmask = s_vmask[tid < 16 * T ? tid : 0] & (has_var ? ~0ULL : 0ULL);
             bool isfree = false;
             int f;
-            if (p.node_pat) {                                       // node mode: chain index = node index
+            if constexpr (NODE) {                                   // node mode: chain index = node index
                 pat = p.node_pat[chain];
                 isfree = (vmask & p.node_free[chain]) != 0;
                 f = (vmask & p.node_zero[chain]) ? 0 : sign_of_var(vmask, pat);
@@ -297,28 +300,28 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 bool bad = false;
                 if (has_var) {
                     const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
-                    if (isfree) bad = !basic && !blocked && (fabs(q) > p.tol);     // free: stationarity only
+                    if (NODE && isfree) bad = !basic && !blocked && (fabs(q) > p.tol);     // free: stationarity only
                     else if (basic) bad = (f == 0) || (fq < -p.tol);
                     else bad = (fq > p.tol) && !blocked;
                 }
                 const unsigned long long bb = __ballot(bad), bs = __ballot(basic);
-                if (lane == 0 && wave < nwords) { s_inf[par * 8 + wave] = bb; s_bas[par * 8 + wave] = bs; }
+                // every wave condenses ITS mask word before the barrier (count in bits 0..7, one bit per 16-variable tile column in
+                // bits 8..11), so that after it each wave combines NW small words instead of re-deriving everything from NW masks
+                unsigned summ = (unsigned)__popcll(bb);
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+                    if ((bb >> (16 * sub)) & 0xFFFFull) summ |= 0x100u << sub;
+                if (lane == 0 && wave < nwords) { s_inf[par * 8 + wave] = bb; s_bas[par * 8 + wave] = bs; s_sum[par * 8 + wave] = summ; }
                 STAMP(9);
                 __syncthreads();
                 STAMP(10);
-                // mask words are read once, reduced to (count, tile mask, largest violator) and dropped
-                int count = 0, single_k = -1;
+                int count = 0;
                 unsigned tiles = 0;
 #pragma unroll
-                for (int w = 0; w < 5; ++w) {
-                    unsigned long long ww = (w < nwords) ? s_inf[par * 8 + w] : 0ULL;
-                    ww = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ww >> 32)) << 32) |
-                         (unsigned)__builtin_amdgcn_readfirstlane((int)ww);             // uniform -> SALU bookkeeping
-                    count += __popcll(ww);
-                    if (ww) single_k = (w << 6) + 63 - __builtin_clzll(ww);
-#pragma unroll
-                    for (int sub = 0; sub < 4; ++sub)
-                        if ((ww >> (16 * sub)) & 0xFFFFull) tiles |= 1u << (4 * w + sub);
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned sw = (unsigned)__builtin_amdgcn_readfirstlane((int)s_sum[par * 8 + w]);    // 0 for w >= nwords
+                    count += (int)(sw & 0xFFu);
+                    tiles |= (sw >> 8) << (4 * w);
                 }
                 STAMP(0);
                 if (count == 0) break;
@@ -327,7 +330,17 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 else if (patience > 0) { --patience; all = true; }
                 else all = false;                                     // backup rule: only the largest violator
                 if (++rounds > p.max_rounds) { ++nunconv; break; }
-                if (!all) tiles = 1u << (single_k >> 4);
+                int single_k = -1;
+                if (!all) {                                           // rare: the largest violator, from the mask words themselves
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        unsigned long long ww = s_inf[par * 8 + w];
+                        ww = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ww >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)ww);
+                        if (ww) single_k = (w << 6) + 63 - __builtin_clzll(ww);
+                    }
+                    tiles = 1u << (single_k >> 4);
+                }
                 tiles = (unsigned)__builtin_amdgcn_readfirstlane((int)tiles);
 
                 while (tiles) {
@@ -339,9 +352,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                     pmall = (unsigned)__builtin_amdgcn_readfirstlane((int)pmall);
                     while (pmall) {
                         // ---- block: the lowest <= MB violators of tile column kappa -------------------------------------
-                        unsigned rest = pmall;
+                        unsigned rest = 0;
+                        if (__builtin_expect(__builtin_popcount(pmall) > MB, 0)) {
+                            rest = pmall;
 #pragma unroll
-                        for (int i = 0; i < MB; ++i) rest &= rest - 1;
+                            for (int i = 0; i < MB; ++i) rest &= rest - 1;
+                        }
                         const unsigned pm = pmall & ~rest;
                         pmall = rest;
                         const int m = __builtin_popcount(pm);
@@ -455,7 +471,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 if (obj2 < bo || (obj2 == bo && (long long)pat < bp)) { s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat; }
             }
         }
-        if (p.node_sol) {
+        if constexpr (NODE) {
             if (has_var) p.node_sol[(size_t)chain * p.node_ld + tid] = basic ? q : 0.0;
             if (tid == 0) p.node_obj2[chain] = corner;
         }
@@ -464,9 +480,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     if (tid == 0) {
         p.best_obj[blockIdx.x] = sqrt(s_best[0]);
         p.best_pat[blockIdx.x] = reinterpret_cast<long long *>(s_best)[1];
-        if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
-        if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
-        if (p.n_vetoes && nveto) atomicAdd(p.n_vetoes, nveto);
+        if (p.n_pivots && npiv) atomicAdd(p.n_pivots, (unsigned long long)npiv);
+        if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, (unsigned long long)nunconv);
+        if (p.n_vetoes && nveto) atomicAdd(p.n_vetoes, (unsigned long long)nveto);
     }
 }
 
@@ -476,12 +492,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
 // are computed from LDS words or kernel arguments that are identical for all 512 threads — never from a half's own registers —
 // so both instantiations execute the same barrier sequence: per scan 1, per block 2 + m (the m panel steps; idle waves only
 // count them).  Any edit that makes a barrier conditional on per-half or per-wave data deadlocks the CU.
-template <int T>
+template <int T, bool NODE>
 __global__ __launch_bounds__(THREADS, 2) void sweep_blk_kernel(SweepParams p)
 {
     const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    if (half == 0) sweep_body<T, 0>(p);
-    else sweep_body<T, 1>(p);
+    if (half == 0) sweep_body<T, 0, NODE>(p);
+    else sweep_body<T, 1, NODE>(p);
 }
 
 // Tfull ((n+1)^2) -> tile-cyclic initial state: [slot = tri(gamma) + rho][256 = a + 16 b], then q0[16 T], then the corner
@@ -523,7 +539,8 @@ hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, h
 template <int T>
 static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(blk::sweep_blk_kernel<T>, dim3(grid), dim3(blk::THREADS), 0, s, p);   // ~100 KB of static LDS
+    if (p.node_pat) hipLaunchKernelGGL((blk::sweep_blk_kernel<T, true>), dim3(grid), dim3(blk::THREADS), 0, s, p);     // ~100 KB of static LDS
+    else hipLaunchKernelGGL((blk::sweep_blk_kernel<T, false>), dim3(grid), dim3(blk::THREADS), 0, s, p);
     return hipGetLastError();
 }
 
