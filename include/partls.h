@@ -103,6 +103,18 @@ partls_status partls_fit_bnb(partls_ctx *ctx, const double *X, int64_t N, int64_
                              const int64_t *P, int64_t K, int64_t ldP, double eta,
                              double *alpha, double *beta, double *t, double *opt, int64_t *nopen);
 
+/* The two primitives of the BnB search on a prepared (PARTLS_OPT_FAITHFUL_INTERCEPT) context — what a host that shards the
+ * frontier across GPUs calls (partitionedls.jl_amd/dist.py: one process per GPU, batches dealt round-robin, one all-gather of
+ * (bound, branch) per batch carries the incumbent).  A node is (pat, free): group k < K+1 is branched iff bit k of free is
+ * clear, then α_pk >= 0 if bit k of pat is set, <= 0 otherwise (BnB.jl:120-121; group K is the intercept's).
+ *   bound: lb[i] = lower bound of node i (BnB.jl:69-92); branch[i] = argmax_k ν_k (BnB.jl:107,117) or -1 when the relaxed
+ *          solution is already feasible (BnB.jl:109-115: lb[i] is then an upper bound too).
+ *   leaf:  model of one feasible node, normalised as BnB.jl:36-39, *opt from the data. */
+partls_status partls_bnb_bound(partls_ctx *ctx, int64_t count, const uint64_t *pat, const uint64_t *free_groups,
+                               double *lb, int32_t *branch);
+partls_status partls_bnb_leaf(partls_ctx *ctx, uint64_t pat, uint64_t free_groups,
+                              double *alpha, double *beta, double *t, double *opt);
+
 /* ---- predict(α, β, t, P, X)  — replaces PartitionedLS.jl:132-134: yhat = X*(P.*α)*β .+ t ------------------------------ */
 partls_status partls_predict(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX,
                              const int64_t *P, int64_t K, int64_t ldP, const double *alpha, const double *beta, double t,

@@ -462,10 +462,16 @@ int oracle_fit_alt(const double *X, int64_t N, int64_t M, const double *y, const
         double rn;
         oracle_nnls(s.Xb, rows, Mp, s.yb, a, &rn, s.w, s.zz, s.index, NULL);
         /* checkalpha (Alt.jl:5-20): a group whose alphas sum to exactly 0 becomes uniform */
+        /* suma and sumP are taken BEFORE any group is rewritten (Alt.jl:6-7): it matters when groups overlap */
         for (int64_t k = 0; k < Kp; ++k) {
-            double suma = 0.0; int64_t sumP = 0;
-            for (int64_t m = 0; m < Mp; ++m) { suma += (double)AT(Po, Mp, m, k) * a[m]; sumP += AT(Po, Mp, m, k); }
-            if (suma == 0.0)
+            double suma = 0.0;
+            for (int64_t m = 0; m < Mp; ++m) suma += (double)AT(Po, Mp, m, k) * a[m];
+            s.beta[k] = suma;
+        }
+        for (int64_t k = 0; k < Kp; ++k) {
+            int64_t sumP = 0;
+            for (int64_t m = 0; m < Mp; ++m) sumP += AT(Po, Mp, m, k);
+            if (s.beta[k] == 0.0)
                 for (int64_t m = 0; m < Mp; ++m) if (AT(Po, Mp, m, k) == 1) a[m] = 1.0 / (double)sumP;
         }
         /* renormalise (Alt.jl:95-98) */
@@ -520,7 +526,8 @@ typedef struct {
     int64_t *index;
 } bnb_ctx;
 
-/* BnB.jl:69-92.  sigma[m] in {0 free, +1 (alpha_m >= 0), -1 (alpha_m <= 0)} encodes Σ. */
+/* BnB.jl:69-92.  sigma[m] encodes Σ as two flags: bit 0 = +m is in Σ (alpha_m >= 0), bit 1 = -m is in Σ (alpha_m <= 0).  Both
+ * can be set when a feature belongs to two branched groups (overlapping partitions): the reference then zeroes both columns. */
 static double bnb_lower_bound(bnb_ctx *c, const int8_t *sigma, double *alpha)
 {
     int64_t rows = c->rows, Mp = c->Mp;
@@ -528,22 +535,22 @@ static double bnb_lower_bound(bnb_ctx *c, const int8_t *sigma, double *alpha)
         const double *src = &AT(c->Xo, rows, 0, m);
         double *dp = &AT(c->XX, rows, 0, m), *dm = &AT(c->XX, rows, 0, Mp + m);
         for (int64_t i = 0; i < rows; ++i) {
-            dp[i] = (sigma[m] < 0) ? 0.0 : src[i];          /* Xp[:, negConstr] .= 0 */
-            dm[i] = (sigma[m] > 0) ? 0.0 : -src[i];         /* Xm[:, posConstr] .= 0 */
+            dp[i] = (sigma[m] & 2) ? 0.0 : src[i];          /* Xp[:, negConstr] .= 0 */
+            dm[i] = (sigma[m] & 1) ? 0.0 : -src[i];         /* Xm[:, posConstr] .= 0 */
         }
     }
     memcpy(c->yb, c->yo, (size_t)rows * sizeof(double));
     double rn;
     oracle_nnls(c->XX, rows, 2 * Mp, c->yb, c->aa, &rn, c->w, c->zz, c->index, NULL);
     for (int64_t m = 0; m < Mp; ++m) {
-        double ap = (sigma[m] < 0) ? 0.0 : c->aa[m];
-        double an = (sigma[m] > 0) ? 0.0 : c->aa[Mp + m];
+        double ap = (sigma[m] & 2) ? 0.0 : c->aa[m];
+        double an = (sigma[m] & 1) ? 0.0 : c->aa[Mp + m];
         alpha[m] = ap - an;
     }
     /* norm(XX*αα - y) with the zeroed columns == norm(Xo*(αp-αn) - y) evaluated on the original data */
     for (int64_t i = 0; i < rows; ++i) c->r[i] = -c->yo[i];
     for (int64_t m = 0; m < Mp; ++m) {
-        double wp = (sigma[m] < 0) ? 0.0 : c->aa[m], wn = (sigma[m] > 0) ? 0.0 : c->aa[Mp + m];
+        double wp = (sigma[m] & 2) ? 0.0 : c->aa[m], wn = (sigma[m] & 1) ? 0.0 : c->aa[Mp + m];
         double wm = wp - wn;
         if (wm == 0.0) continue;
         const double *src = &AT(c->Xo, rows, 0, m);
@@ -592,10 +599,10 @@ static double bnb_node(bnb_ctx *c, double mu, int8_t *sigma, double *out, int64_
     memcpy(saved, sigma, (size_t)Mp);
     double *ap = malloc((size_t)Mp * sizeof(double)), *am = malloc((size_t)Mp * sizeof(double));
     int64_t np_ = 0, nm_ = 0;
-    for (int64_t m = 0; m < Mp; ++m) if (AT(c->Po, Mp, m, kbest) == 1) sigma[m] = +1;
+    for (int64_t m = 0; m < Mp; ++m) if (AT(c->Po, Mp, m, kbest) == 1) sigma[m] |= 1;      /* Σp = [Σ; pk] */
     double mup = bnb_node(c, mu, sigma, ap, &np_);
     memcpy(sigma, saved, (size_t)Mp);
-    for (int64_t m = 0; m < Mp; ++m) if (AT(c->Po, Mp, m, kbest) == 1) sigma[m] = -1;
+    for (int64_t m = 0; m < Mp; ++m) if (AT(c->Po, Mp, m, kbest) == 1) sigma[m] |= 2;      /* Σm = [Σ; -pk] */
     double mum = bnb_node(c, mu < mup ? mu : mup, sigma, am, &nm_);
     memcpy(sigma, saved, (size_t)Mp);
     /* argmin([μ, μp, μm]) first index; index 0 returns this node's relaxed α with value μ (BnB.jl:126-128) */

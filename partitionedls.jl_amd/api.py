@@ -164,6 +164,26 @@ class Context:
         _check(L.lib().partls_bnb_prepared(self._h, _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
         return a, b, t.value, o.value, no.value
 
+    def bnb_bound(self, pats, frees):
+        """Bound a batch of BnB nodes (pat[i], free[i]) on a prepared faithful context: (lb[count], branch[count])."""
+        pats = np.ascontiguousarray(pats, dtype=np.uint64)
+        frees = np.ascontiguousarray(frees, dtype=np.uint64)
+        n = len(pats)
+        lb = np.zeros(n)
+        br = np.zeros(n, dtype=np.int32)
+        if n:
+            _check(L.lib().partls_bnb_bound(self._h, n, pats.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            frees.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(lb),
+                                            br.ctypes.data_as(C.POINTER(C.c_int32))))
+        return lb, br
+
+    def bnb_leaf(self, pat, free):
+        N, M, K = self._shape
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double()
+        _check(L.lib().partls_bnb_leaf(self._h, C.c_uint64(int(pat)), C.c_uint64(int(free)), _dp(a), _dp(b), C.byref(t), C.byref(o)))
+        return a, b, t.value, o.value
+
     def timing(self, which):
         ms = C.c_double()
         _check(L.lib().partls_get_timing(self._h, int(which), C.byref(ms)))

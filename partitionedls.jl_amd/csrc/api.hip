@@ -160,20 +160,28 @@ static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
     return launch_sweep_generic(p, grid, c->stream);
 }
 
-partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const std::vector<uint64_t> &free_,
-                          const std::vector<uint64_t> &zero, std::vector<double> &sols, std::vector<double> &obj2,
-                          unsigned long long *unconv, bool resume)
+void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes)
+{
+    // multiplier of Opt.jl:28-29: f_m = sum_k P[m,k] s_k; only its sign matters for the constraint f_m w_m >= 0 (0: column is zero)
+    codes.resize((size_t)c->n);
+    for (int i = 0; i < c->n; ++i) {
+        const uint64_t m = c->mask_tab[(size_t)i];
+        const int f = 2 * __builtin_popcountll(m & pattern) - __builtin_popcountll(m);
+        codes[(size_t)i] = (int8_t)((f > 0) - (f < 0));
+    }
+}
+
+partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_t cnt, std::vector<double> &sols,
+                          std::vector<double> &obj2, unsigned long long *unconv, bool resume)
 {
     const int n = c->n, ld = n + 1;
-    const size_t cnt = pat.size();
     sols.assign(cnt * (size_t)n, 0.0);
     obj2.assign(cnt, 0.0);
     if (unconv) *unconv = 0;
     if (cnt == 0) return PARTLS_OK;
+    if (codes.size() != cnt * (size_t)n) { set_error("solve_nodes: code array has the wrong size"); return PARTLS_ERR_BAD_ARG; }
     const int grid = (int)std::min<size_t>(cnt, c->use_reg ? 2048 : 512);
-    PARTLS_HIP_CHECK(c->nodePat.ensure(cnt * sizeof(uint64_t)));
-    PARTLS_HIP_CHECK(c->nodeFree.ensure(cnt * sizeof(uint64_t)));
-    PARTLS_HIP_CHECK(c->nodeZero.ensure(cnt * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(c->nodeCode.ensure(cnt * (size_t)n));
     PARTLS_HIP_CHECK(c->nodeSol.ensure(cnt * (size_t)n * sizeof(double)));
     PARTLS_HIP_CHECK(c->nodeObj.ensure(cnt * sizeof(double)));
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
@@ -190,9 +198,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
         else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
     }
     PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodePat.p, pat.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeFree.p, free_.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeZero.p, zero.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeCode.p, codes.data(), cnt * (size_t)n, hipMemcpyHostToDevice, c->stream));
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
     p.mask = c->maskTabD.as<uint64_t>();
@@ -204,7 +210,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const
     p.n_unconverged = c->counters.as<unsigned long long>();
     p.n_pivots = c->counters.as<unsigned long long>() + 1;
     p.n_vetoes = c->counters.as<unsigned long long>() + 2;
-    p.node_pat = c->nodePat.as<uint64_t>(); p.node_free = c->nodeFree.as<uint64_t>(); p.node_zero = c->nodeZero.as<uint64_t>();
+    p.node_code = c->nodeCode.as<int8_t>();
     p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
     if (coop) {
         // one large problem: many workgroups cooperate on a single global-memory tableau (sweep_coop.hip)
@@ -430,7 +436,7 @@ void partls_destroy(partls_ctx *c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
-                          &c->flag, &c->yhatD, &c->gD, &c->nodePat, &c->nodeFree, &c->nodeZero, &c->nodeSol, &c->nodeObj,
+                          &c->flag, &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj,
                           &c->predX, &c->predY};
         for (DevBuf *b : bufs) b->release();
         for (int w = 0; w < PARTLS_T_COUNT; ++w) {
@@ -544,7 +550,9 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     unsigned long long unconv = 0;
     t_begin(c, PARTLS_T_FINISH);
     const auto f0 = std::chrono::steady_clock::now();
-    partls_status st = solve_nodes(c, {(uint64_t)pattern & kmask}, {0}, {0}, sols, obj2, &unconv);
+    std::vector<int8_t> codes;
+    opt_codes(c, (uint64_t)pattern & kmask, codes);
+    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
     const auto f1 = std::chrono::steady_clock::now();
     unscale_solution(c, sols.data(), w);
@@ -554,6 +562,11 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     uint64_t full = (uint64_t)pattern & kmask;
     if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
     else full = (uint64_t)pattern;
+    // A group without any feature leaves the subproblem unchanged: the reference then sees bitwise equal objectives for the two
+    // patterns and argmin keeps the first, i.e. the one with that group's bit clear (Opt.jl:96)
+    uint64_t used = 1ULL << c->K;
+    for (int64_t m = 0; m < c->M; ++m) used |= c->mask_aug[(size_t)m];
+    full &= used;
     st = data_objective(c, w, opt);
     if (c->knobs.finish_trace) {
         const auto f3 = std::chrono::steady_clock::now();
@@ -578,7 +591,9 @@ partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alp
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     std::vector<double> sols, obj2, w;
     unsigned long long unconv = 0;
-    partls_status st = solve_nodes(c, {(uint64_t)pattern}, {0}, {0}, sols, obj2, &unconv);
+    std::vector<int8_t> codes;
+    opt_codes(c, (uint64_t)pattern, codes);
+    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
     unscale_solution(c, sols.data(), w);
     st = refine_solution(c, w, false);

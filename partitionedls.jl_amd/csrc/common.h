@@ -41,13 +41,13 @@ struct SweepParams {
     unsigned long long *n_unconverged;   // patterns that hit max_rounds
     unsigned long long *n_pivots;        // total pivots on the (n+1)^2 tableau (diagnostics / flop accounting)
     unsigned long long *n_vetoes;        // entering pivots refused by the leave-one-out rule (diagnostics)
-    // Node mode (Alt alpha-steps, BnB node bounds): when node_pat != nullptr chain c is ONE subproblem with its own
-    // pattern node_pat[c], free groups node_free[c] (no sign constraint: BnB's relaxed groups, BnB.jl:70-79) and zero
-    // groups node_zero[c] (multiplier 0, e.g. beta_k == 0 in Alt.jl:80-81).  chain_len must be 1.  Outputs per node:
+    // Node mode (Alt alpha-steps, BnB node bounds): when node_code != nullptr chain c is ONE subproblem whose constraint on
+    // tableau variable v is node_code[c * node_ld + v]:  +1 (w_v >= 0), -1 (w_v <= 0), 0 (w_v = 0: zero multiplier, or both
+    // sign constraints of an overlapping partition), 2 (free: BnB's not yet branched groups, BnB.jl:70-79).  Per VARIABLE, not
+    // per group: Alt's multipliers sum_k P[m,k] beta_k (Alt.jl:80-81) and BnB's accumulated constraints (BnB.jl:120-121) are
+    // not functions of a group sign pattern once a feature sits in two groups.  chain_len must be 1.  Outputs per node:
     // node_sol[c * node_ld + v] = scaled solution (0 for nonbasic), node_obj2[c] = objective^2.
-    const uint64_t *node_pat;
-    const uint64_t *node_free;
-    const uint64_t *node_zero;
+    const int8_t *node_code;
     double *node_sol;
     double *node_obj2;
     int node_ld;

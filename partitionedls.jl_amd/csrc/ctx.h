@@ -55,7 +55,7 @@ struct partls_ctx {
     // gram
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
-        wdev, partial, flag, yhatD, gD, nodePat, nodeFree, nodeZero, nodeSol, nodeObj, predX, predY;
+        wdev, partial, flag, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY;
     std::vector<double> hG, hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
     int n = 0, kbits = 0, T = 0;
@@ -77,12 +77,13 @@ void t_collect(partls_ctx *c);
 partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int x_on_device,
                           const int64_t *P, int64_t K, int64_t ldP, double eta, bool faithful, uint32_t flags);
 
-// Solve a batch of independent subproblems ("nodes") from the fresh tableau: node i has sign pattern pat[i] (bit k = sign
-// of group k), free groups free_[i] (no sign constraint) and zero groups zero[i] (multiplier 0).  sols: count x n scaled
-// solutions in tableau order (0 for nonbasic); obj2: objective^2 from the tableau corner.
-partls_status solve_nodes(partls_ctx *c, const std::vector<uint64_t> &pat, const std::vector<uint64_t> &free_,
-                          const std::vector<uint64_t> &zero, std::vector<double> &sols, std::vector<double> &obj2,
-                          unsigned long long *unconv, bool resume = false);
+// Solve a batch of `cnt` independent subproblems ("nodes") from the fresh tableau.  codes[i * n + v] is the constraint on
+// tableau variable v in node i: +1 (w >= 0), -1 (w <= 0), 0 (w = 0), 2 (free) — see SweepParams::node_code.  sols: cnt x n
+// scaled solutions in tableau order (0 for nonbasic); obj2: objective^2 from the tableau corner.
+partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_t cnt, std::vector<double> &sols,
+                          std::vector<double> &obj2, unsigned long long *unconv, bool resume = false);
+// node codes of one Opt sign pattern (Opt.jl:28-29): sign of the multiplier sum_k P[m,k] s_k of every tableau variable
+void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes);
 
 // scaled tableau solution -> w over [features, intercept] (length M+1); a free intercept is recovered from the Gram copy
 void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w);

@@ -2,13 +2,15 @@
 //
 // Both reduce to batches of sign-constrained least-squares "nodes" on the shared Gram block, solved on the device by the
 // sweep kernels in node mode (solve_nodes, api.hip):
-//   * Alt α-step (Alt.jl:80-90):  nonneg_lsq(Xo .* (Po β)', y) has the constraint set {Xo w : sign(β_g(m)) w_m >= 0}, i.e. it
-//     is the Opt subproblem of the sign pattern of β (groups with β_k == 0 have a zero column: α stays 0); α_m = w_m / β_g(m).
+//   * Alt α-step (Alt.jl:80-90):  nonneg_lsq(Xo .* f', y) with f_m = sum_k Po[m,k] β_k has the constraint set
+//     {Xo w : sign(f_m) w_m >= 0} (f_m == 0: zero column, α_m stays 0); α_m = w_m / f_m.  Any 0/1 partition matrix, as in the
+//     reference: for a feature in several groups f_m is not a function of the sign pattern of β, hence per-variable codes.
 //   * Alt β-step (Alt.jl:109-110): (Xo (Po∘α)) \ yo  ==  solve (A' G A) β = A' c  with A = Po∘α — (K+1)^2, on the host
 //     from the device-built Gram copy, like cleanupResult an O(K^3) epilogue.
 //   * BnB node bound (BnB.jl:69-92): the [Xp Xm] doubling is NNLS's way of writing free variables; a node is the same
 //     tableau problem with the not-yet-branched groups FREE.  Nodes are bounded in batches (best-first frontier), the
-//     incumbent prunes (BnB.jl:102); the node count depends on the search order and is not a parity quantity.
+//     incumbent prunes (BnB.jl:102); the node count depends on the search order and is not a parity quantity.  A feature of
+//     several groups collects one constraint per branched group (BnB.jl:120-121): opposite ones force it to 0.
 #include "ctx.h"
 #include <chrono>
 #include <cstdio>
@@ -20,20 +22,6 @@
 using namespace partls;
 
 namespace {
-
-// every feature must belong to at most one group for the group-pattern encoding of multipliers to be exact
-bool proper_partition(const partls_ctx *c)
-{
-    for (int64_t m = 0; m < c->M; ++m)
-        if (__builtin_popcountll(c->mask_aug[(size_t)m]) > 1) return false;
-    return true;
-}
-
-int group_of(const partls_ctx *c, int64_t m)          // -1: in no group
-{
-    const uint64_t mk = c->mask_aug[(size_t)m];
-    return mk ? __builtin_ctzll(mk) : -1;
-}
 
 // w'Gw - 2 w'c + yy on the regularised host Gram copy (w over [features, intercept])
 double gram_objective2(const partls_ctx *c, const std::vector<double> &w)
@@ -100,63 +88,71 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     partls_status st = PARTLS_OK;
     const int64_t M = c->M, K = c->K;
-    if (!proper_partition(c)) { set_error("partls_fit_alt: a feature belongs to more than one group (overlapping partitions are not supported on the device path)"); return PARTLS_ERR_UNSUPPORTED; }
     const int Mp = (int)M + 1, Kp = (int)K + 1, Y = (int)M + 1;
-    std::vector<double> a(alpha0, alpha0 + Mp), b(beta0, beta0 + Kp), w((size_t)Mp, 0.0), sols, obj2;
-    std::vector<int> grp((size_t)Mp);
-    for (int m = 0; m < Mp; ++m) grp[(size_t)m] = group_of(c, m);
-    auto w_from = [&]() { for (int m = 0; m < Mp; ++m) w[(size_t)m] = (grp[(size_t)m] >= 0) ? a[(size_t)m] * b[(size_t)grp[(size_t)m]] : 0.0; };
+    std::vector<double> a(alpha0, alpha0 + Mp), b(beta0, beta0 + Kp), w((size_t)Mp, 0.0), f((size_t)Mp, 0.0), sols, obj2;
+    // Po as lists: groups of every variable (features, then the intercept in its own group K; PartitionedLS.jl:76-81)
+    std::vector<std::vector<int>> groups_of((size_t)Mp);
+    for (int m = 0; m < Mp; ++m)
+        for (int k = 0; k < Kp; ++k) if ((c->mask_aug[(size_t)m] >> k) & 1ULL) groups_of[(size_t)m].push_back(k);
+    auto feature_mul = [&]() {                            // f_m = sum_k Po[m,k] β_k   (Alt.jl:80)
+        for (int m = 0; m < Mp; ++m) { double v = 0.0; for (int k : groups_of[(size_t)m]) v += b[(size_t)k]; f[(size_t)m] = v; }
+    };
+    auto w_from = [&]() { feature_mul(); for (int m = 0; m < Mp; ++m) w[(size_t)m] = a[(size_t)m] * f[(size_t)m]; };
+    std::vector<int8_t> codes((size_t)c->n);
 
     double oldopt = 1e20, optval = 1e10;                 // Alt.jl:73-74
     int64_t i = 1;
     unsigned long long unconv_total = 0;
     while (i <= T && std::fabs(oldopt - optval) > eps * oldopt) {
         // ---- α-step: one sign-constrained solve on the device (Alt.jl:80-90) ----------------------------------------------
-        uint64_t pat = 0, zero = 0;
-        for (int k = 0; k < Kp; ++k) { if (b[(size_t)k] > 0.0) pat |= 1ULL << k; else if (b[(size_t)k] == 0.0) zero |= 1ULL << k; }
+        feature_mul();
+        for (int v = 0; v < c->n; ++v) { const double fv = f[(size_t)c->perm[(size_t)v]]; codes[(size_t)v] = (int8_t)((fv > 0.0) - (fv < 0.0)); }
         unsigned long long unconv = 0;
         const auto tt0 = std::chrono::steady_clock::now();
-        st = solve_nodes(c, {pat}, {0}, {zero}, sols, obj2, &unconv, /*resume=*/i > 1);   // warm start after the first α-step
+        st = solve_nodes(c, codes, 1, sols, obj2, &unconv, /*resume=*/i > 1);   // warm start after the first α-step
         const auto tt1 = std::chrono::steady_clock::now();
         if (st != PARTLS_OK) return st;
         unconv_total += unconv;
         std::vector<double> wv;
         unscale_solution(c, sols.data(), wv);
         for (int m = 0; m < Mp; ++m) {
-            const double f = (grp[(size_t)m] >= 0) ? b[(size_t)grp[(size_t)m]] : 0.0;
-            const double am = (f != 0.0) ? wv[(size_t)m] / f : 0.0;
+            const double am = (f[(size_t)m] != 0.0) ? wv[(size_t)m] / f[(size_t)m] : 0.0;
             a[(size_t)m] = am > 0.0 ? am : 0.0;
         }
         // ---- checkalpha (Alt.jl:5-20) and renormalisation (Alt.jl:95-98) ----------------------------------------------------
-        std::vector<double> suma((size_t)Kp, 0.0);
+        std::vector<double> suma((size_t)Kp, 0.0), poa((size_t)Mp, 0.0);
         std::vector<int> cntk((size_t)Kp, 0);
-        for (int m = 0; m < Mp; ++m) if (grp[(size_t)m] >= 0) { suma[(size_t)grp[(size_t)m]] += a[(size_t)m]; ++cntk[(size_t)grp[(size_t)m]]; }
-        for (int m = 0; m < Mp; ++m) { const int g = grp[(size_t)m]; if (g >= 0 && suma[(size_t)g] == 0.0) a[(size_t)m] = 1.0 / (double)cntk[(size_t)g]; }
+        for (int m = 0; m < Mp; ++m) for (int k : groups_of[(size_t)m]) { suma[(size_t)k] += a[(size_t)m]; ++cntk[(size_t)k]; }
+        for (int k = 0; k < Kp; ++k)
+            if (suma[(size_t)k] == 0.0)
+                for (int m = 0; m < Mp; ++m) if ((c->mask_aug[(size_t)m] >> k) & 1ULL) a[(size_t)m] = 1.0 / (double)cntk[(size_t)k];
         std::fill(suma.begin(), suma.end(), 0.0);
-        for (int m = 0; m < Mp; ++m) if (grp[(size_t)m] >= 0) suma[(size_t)grp[(size_t)m]] += a[(size_t)m];
-        for (int m = 0; m < Mp; ++m) { const int g = grp[(size_t)m]; if (g >= 0) a[(size_t)m] /= suma[(size_t)g]; }
+        for (int m = 0; m < Mp; ++m) for (int k : groups_of[(size_t)m]) suma[(size_t)k] += a[(size_t)m];          // sumα
+        for (int m = 0; m < Mp; ++m) for (int k : groups_of[(size_t)m]) poa[(size_t)m] += suma[(size_t)k];        // Po * sumα'
+        for (int m = 0; m < Mp; ++m) a[(size_t)m] /= poa[(size_t)m];                 // a feature in no group: 0/0 = NaN, as in the reference
         for (int k = 0; k < Kp; ++k) b[(size_t)k] *= suma[(size_t)k];
         // ---- β-step: (A' G A) β = A' c,  A = Po∘α  (Alt.jl:109-110 in Gram form) ---------------------------------------------
-        std::vector<double> H((size_t)Kp * Kp, 0.0), g((size_t)Kp, 0.0);
+        std::vector<double> H((size_t)Kp * Kp, 0.0), g((size_t)Kp, 0.0), ga((size_t)Kp, 0.0);
         for (int m = 0; m < Mp; ++m) {
-            const int gm = grp[(size_t)m];
-            if (gm < 0 || a[(size_t)m] == 0.0) continue;
-            g[(size_t)gm] += a[(size_t)m] * h_reg(c, m, Y);
+            if (groups_of[(size_t)m].empty() || a[(size_t)m] == 0.0) continue;
+            const double am = a[(size_t)m];
+            for (int k : groups_of[(size_t)m]) g[(size_t)k] += am * h_reg(c, m, Y);
+            // row m of G A: (G A)[m][k2] = sum_{m2} G[m][m2] a_{m2} [m2 in k2]
+            std::fill(ga.begin(), ga.end(), 0.0);
             if (c->eta == 0.0) {                                   // plain Gram row: no per-entry call (M^2 entries per iteration)
                 const double *Grow = &c->hG[(size_t)m * c->ldg];
-                double *Hrow = &H[(size_t)gm * Kp];
-                const double am = a[(size_t)m];
                 for (int m2 = 0; m2 < Mp; ++m2) {
-                    const int g2 = grp[(size_t)m2];
-                    if (g2 >= 0) Hrow[g2] += am * Grow[m2] * a[(size_t)m2];
+                    const double v = Grow[m2] * a[(size_t)m2];
+                    for (int k2 : groups_of[(size_t)m2]) ga[(size_t)k2] += v;
                 }
             } else {
                 for (int m2 = 0; m2 < Mp; ++m2) {
-                    const int g2 = grp[(size_t)m2];
-                    if (g2 < 0 || a[(size_t)m2] == 0.0) continue;
-                    H[(size_t)gm * Kp + g2] += a[(size_t)m] * h_reg(c, m, m2) * a[(size_t)m2];
+                    if (a[(size_t)m2] == 0.0) continue;
+                    const double v = h_reg(c, m, m2) * a[(size_t)m2];
+                    for (int k2 : groups_of[(size_t)m2]) ga[(size_t)k2] += v;
                 }
             }
+            for (int k : groups_of[(size_t)m]) for (int k2 = 0; k2 < Kp; ++k2) H[(size_t)k * Kp + k2] += am * ga[(size_t)k2];
         }
         // groups without members (possible only for user groups with no feature) get a unit diagonal so H stays regular
         for (int k = 0; k < Kp; ++k) if (H[(size_t)k * Kp + k] == 0.0) H[(size_t)k * Kp + k] = 1.0;
@@ -192,30 +188,106 @@ partls_status partls_fit_bnb(partls_ctx *c, const double *X, int64_t N, int64_t 
     return partls_bnb_prepared(c, alpha, beta, t, opt, nopen);
 }
 
+// ---- BnB primitives (shared by the single-rank driver below and the rank-sharded search of partitionedls.jl_amd/dist.py) -------
+// A node is (pat, free): group k is branched iff bit k of `free` is clear, and then constrained to alpha_pk >= 0 (bit k of pat
+// set) or <= 0 (BnB.jl:120-121).  partls_bnb_bound evaluates BnB.jl:99-118 for a batch: lb[i] = the node's lower bound
+// (BnB.jl:69-92 on the device) and branch[i] = argmax_k nu_k (BnB.jl:107,117), or -1 when all nu_k == 0, i.e. the relaxed
+// solution is feasible for the original problem and lb[i] is its value (BnB.jl:109-115).
+partls_status partls_bnb_bound(partls_ctx *c, int64_t count, const uint64_t *pat, const uint64_t *free_, double *lb, int32_t *branch)
+{
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (count < 0 || (count > 0 && (!pat || !free_ || !lb || !branch))) { set_error("partls_bnb_bound: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    const int Mp = (int)c->M + 1, Kp = (int)c->K + 1, n = c->n;
+    // per-variable constraint of a node: the branched groups of the variable each contribute alpha >= 0 or alpha <= 0 (the Σ of
+    // BnB.jl:120-121 accumulates them); none -> free, both kinds -> the variable is forced to 0 (BnB.jl:74-79)
+    std::vector<int8_t> codes((size_t)count * (size_t)n);
+    for (int64_t i = 0; i < count; ++i)
+        for (int v = 0; v < n; ++v) {
+            const uint64_t br = c->mask_tab[(size_t)v] & ~free_[i];
+            const bool pos = (br & pat[i]) != 0, neg = (br & ~pat[i]) != 0;
+            codes[(size_t)i * (size_t)n + v] = (int8_t)(!br ? 2 : (pos && neg ? 0 : (pos ? 1 : -1)));
+        }
+    std::vector<double> sols, obj2, w;
+    unsigned long long unconv = 0;
+    partls_status st = solve_nodes(c, codes, (size_t)count, sols, obj2, &unconv);
+    if (st != PARTLS_OK) return st;
+    for (int64_t i = 0; i < count; ++i) {
+        lb[i] = std::sqrt(obj2[(size_t)i] > 0.0 ? obj2[(size_t)i] : 0.0);
+        unscale_solution(c, sols.data() + (size_t)i * (size_t)n, w);
+        // nu_k = sum_{i<j in group k} max(0, -w_i w_j) = (sum w+)(sum |w-|)  (BnB.jl:42-57); only free groups can mix signs
+        int kbest = -1; double nubest = 0.0;
+        for (int k = 0; k < Kp; ++k) {
+            if (!((free_[i] >> k) & 1ULL)) continue;
+            double pos = 0.0, neg = 0.0;
+            for (int m = 0; m < Mp; ++m)
+                if ((c->mask_aug[(size_t)m] >> k) & 1ULL) { if (w[(size_t)m] > 0.0) pos += w[(size_t)m]; else neg -= w[(size_t)m]; }
+            const double nu = pos * neg;
+            if (nu > nubest) { nubest = nu; kbest = k; }                   // argmax: first maximal index
+        }
+        branch[i] = kbest;
+    }
+    if (unconv) { set_error("partls_bnb_bound: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+
+// The model of one (feasible) node: re-solve, data-space refinement, BnB.jl:36-39 normalisation, objective from the data.
+partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, double *alpha, double *beta, double *t, double *opt)
+{
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_leaf: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (!alpha || !beta || !t || !opt) { set_error("partls_bnb_leaf: NULL argument"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    const int64_t M = c->M, K = c->K;
+    const int Mp = (int)M + 1, Kp = (int)K + 1, n = c->n;
+    std::vector<int8_t> codes((size_t)n);
+    for (int v = 0; v < n; ++v) {
+        const uint64_t br = c->mask_tab[(size_t)v] & ~free_;
+        const bool pos = (br & pat) != 0, neg = (br & ~pat) != 0;
+        codes[(size_t)v] = (int8_t)(!br ? 2 : (pos && neg ? 0 : (pos ? 1 : -1)));
+    }
+    std::vector<double> sols, obj2, w;
+    unsigned long long unconv = 0;
+    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv);
+    if (st != PARTLS_OK) return st;
+    unscale_solution(c, sols.data(), w);
+    st = refine_solution(c, w, false);
+    if (st != PARTLS_OK) return st;
+    // BnB.jl:36-37: β = sum(Po .* α, dims = 1); α = sum(Po .* α ./ β, dims = 2); t = β[end]
+    std::vector<double> bsum((size_t)Kp, 0.0);
+    for (int m = 0; m < Mp; ++m) for (int k = 0; k < Kp; ++k) if ((c->mask_aug[(size_t)m] >> k) & 1ULL) bsum[(size_t)k] += w[(size_t)m];
+    for (int64_t m = 0; m < M; ++m) {
+        double s = 0.0;
+        for (int k = 0; k < Kp; ++k) if ((c->mask_aug[(size_t)m] >> k) & 1ULL) s += w[(size_t)m] / bsum[(size_t)k];
+        alpha[m] = s;
+    }
+    for (int64_t k = 0; k < K; ++k) beta[k] = bsum[(size_t)k];
+    *t = bsum[(size_t)K];
+    st = data_objective(c, w, opt);
+    if (st != PARTLS_OK) return st;
+    if (unconv) { set_error("partls_bnb_leaf: the node solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+
+// fit_BnB (BnB.jl:94-132) as a best-first search: frontier ordered by the parent's bound, nodes bounded in device batches of 512,
+// the incumbent prunes (BnB.jl:102).  Same optimum as the reference's depth-first recursion; the node count is not.
 partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
 {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_prepared: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (!alpha || !beta || !t || !opt) { set_error("partls_fit_bnb: NULL argument"); return PARTLS_ERR_BAD_ARG; }
-    PARTLS_HIP_CHECK(hipSetDevice(c->device));
-    partls_status st = PARTLS_OK;
-    const int64_t M = c->M, K = c->K;
-    if (!proper_partition(c)) { set_error("partls_fit_bnb: a feature belongs to more than one group (overlapping partitions are not supported on the device path)"); return PARTLS_ERR_UNSUPPORTED; }
-    const int Mp = (int)M + 1, Kp = (int)K + 1;
-    std::vector<int> grp((size_t)Mp);
-    for (int m = 0; m < Mp; ++m) grp[(size_t)m] = group_of(c, m);
-
+    const int Kp = (int)c->K + 1;
     struct Node { double key; uint64_t pat, free_; unsigned long long seq; };
     struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
-    std::priority_queue<Node, std::vector<Node>, Cmp> frontier;           // best-first on the parent's bound
+    std::priority_queue<Node, std::vector<Node>, Cmp> frontier;
     unsigned long long seq = 0;
     frontier.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, seq++});            // root: everything free (Σ = [], BnB.jl:33)
     double mu = INFINITY;
-    std::vector<double> best_w;
+    uint64_t best_pat = 0, best_free = 0;
+    bool have = false;
     int64_t bounded = 0;
-    unsigned long long unconv_total = 0;
     const size_t BATCH = 512;
-    std::vector<uint64_t> bp, bf, bz;
-    std::vector<double> sols, obj2, w;
+    std::vector<uint64_t> bp, bf;
+    std::vector<double> lb;
+    std::vector<int32_t> br;
     while (!frontier.empty()) {
         bp.clear(); bf.clear();
         while (!frontier.empty() && bp.size() < BATCH) {
@@ -225,52 +297,21 @@ partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, do
             bp.push_back(nd.pat); bf.push_back(nd.free_);
         }
         if (bp.empty()) break;
-        bz.assign(bp.size(), 0ULL);
-        unsigned long long unconv = 0;
-        st = solve_nodes(c, bp, bf, bz, sols, obj2, &unconv);
+        lb.resize(bp.size()); br.resize(bp.size());
+        partls_status st = partls_bnb_bound(c, (int64_t)bp.size(), bp.data(), bf.data(), lb.data(), br.data());
         if (st != PARTLS_OK) return st;
-        unconv_total += unconv;
         for (size_t i = 0; i < bp.size(); ++i) {
             ++bounded;
-            const double lb = std::sqrt(obj2[i] > 0.0 ? obj2[i] : 0.0);
-            if (lb >= mu) continue;                                        // BnB.jl:102
-            unscale_solution(c, sols.data() + i * (size_t)c->n, w);
-            // ν_k = Σ_{i<j in group k} max(0, -w_i w_j)  (BnB.jl:42-57); only free groups can mix signs
-            double wmax = 0.0;
-            for (int m = 0; m < Mp; ++m) wmax = std::max(wmax, std::fabs(w[(size_t)m]));
-            const double tiny = 1e-12 * wmax;
-            int kbest = -1; double nubest = 0.0;
-            for (int k = 0; k < Kp; ++k) {
-                if (!((bf[i] >> k) & 1ULL)) continue;
-                double pos = 0.0, neg = 0.0;                               // Σ_{i<j} max(0,-w_i w_j) = (Σ w+)(Σ |w-|)
-                for (int m = 0; m < Mp; ++m)
-                    if (grp[(size_t)m] == k && std::fabs(w[(size_t)m]) > tiny) { if (w[(size_t)m] > 0.0) pos += w[(size_t)m]; else neg -= w[(size_t)m]; }
-                const double nu = pos * neg;
-                if (nu > nubest) { nubest = nu; kbest = k; }               // argmax: first maximal index
-            }
-            if (kbest < 0) {                                               // feasible for the original problem (BnB.jl:109-115)
-                if (lb < mu) { mu = lb; best_w = w; }
-                continue;
-            }
-            const uint64_t bit = 1ULL << kbest;
-            frontier.push({lb, bp[i] | bit, bf[i] & ~bit, seq++});         // α_pk >= 0 first (BnB.jl:120,123)
-            frontier.push({lb, bp[i] & ~bit, bf[i] & ~bit, seq++});        // α_pk <= 0
+            if (lb[i] >= mu) continue;                                     // BnB.jl:102
+            if (br[i] < 0) { mu = lb[i]; best_pat = bp[i]; best_free = bf[i]; have = true; continue; }   // BnB.jl:109-115
+            const uint64_t bit = 1ULL << br[i];
+            frontier.push({lb[i], bp[i] | bit, bf[i] & ~bit, seq++});      // α_pk >= 0 first (BnB.jl:120,123)
+            frontier.push({lb[i], bp[i] & ~bit, bf[i] & ~bit, seq++});     // α_pk <= 0
         }
     }
-    if (best_w.empty()) { set_error("partls_fit_bnb: no feasible leaf found"); return PARTLS_ERR_NOT_CONVERGED; }
-    st = refine_solution(c, best_w, false);
-    if (st != PARTLS_OK) return st;
-    // BnB.jl:36-39: β_k = Σ_{m∈k} α_m (signed); α_m ← α_m / β_k; t = β[end]
-    std::vector<double> bsum((size_t)Kp, 0.0);
-    for (int m = 0; m < Mp; ++m) if (grp[(size_t)m] >= 0) bsum[(size_t)grp[(size_t)m]] += best_w[(size_t)m];
-    for (int64_t m = 0; m < M; ++m) alpha[m] = (grp[(size_t)m] >= 0) ? best_w[(size_t)m] / bsum[(size_t)grp[(size_t)m]] : 0.0;
-    for (int64_t k = 0; k < K; ++k) beta[k] = bsum[(size_t)k];
-    *t = bsum[(size_t)K];
-    st = data_objective(c, best_w, opt);
-    if (st != PARTLS_OK) return st;
+    if (!have) { set_error("partls_fit_bnb: no feasible leaf found"); return PARTLS_ERR_NOT_CONVERGED; }
     if (nopen) *nopen = bounded;
-    if (unconv_total) { set_error("partls_fit_bnb: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
-    return PARTLS_OK;
+    return partls_bnb_leaf(c, best_pat, best_free, alpha, beta, t, opt);
 }
 
 }  // extern "C"

@@ -279,10 +279,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             const uint64_t vmask = s_vmask[tid < 16 * T ? tid : 0] & (has_var ? ~0ULL : 0ULL);
             bool isfree = false;
             int f;
-            if constexpr (NODE) {                                   // node mode: chain index = node index
-                pat = p.node_pat[chain];
-                isfree = (vmask & p.node_free[chain]) != 0;
-                f = (vmask & p.node_zero[chain]) ? 0 : sign_of_var(vmask, pat);
+            if constexpr (NODE) {                                   // node mode: chain index = node index, per-variable codes
+                pat = (uint64_t)chain;
+                const int code = has_var ? (int)p.node_code[(size_t)chain * p.node_ld + tid] : 0;
+                isfree = code == 2;
+                f = isfree ? 0 : code;
             } else {
                 f = sign_of_var(vmask, pat);
             }
@@ -464,8 +465,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             // patterns are ranked on objective^2 (the tableau corner; sqrt is monotone): one sqrt per workgroup instead of one per
             // pattern, unless every pattern's objective is wanted
             const double obj2 = corner > 0.0 ? corner : 0.0;
-            if (p.all_opt && tid == 0) p.all_opt[pat] = sqrt(obj2);
-            if (tid == 0) {                                          // lexicographic (objective, pattern) minimum: argmin's first-index rule
+            // bookkeeping of the finished pattern: by the last thread — its wave owns no panel row and has slack, wave 0 has none
+            if (p.all_opt && tid == THREADS - 1) p.all_opt[pat] = sqrt(obj2);
+            if (tid == THREADS - 1) {                                // lexicographic (objective, pattern) minimum: argmin's first-index rule
                 const double bo = s_best[0];
                 const long long bp = reinterpret_cast<long long *>(s_best)[1];
                 if (obj2 < bo || (obj2 == bo && (long long)pat < bp)) { s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat; }
@@ -477,6 +479,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
         }
     }
     STAMP_FLUSH;
+    __syncthreads();                                      // s_best was last written by thread THREADS - 1
     if (tid == 0) {
         p.best_obj[blockIdx.x] = sqrt(s_best[0]);
         p.best_pat[blockIdx.x] = reinterpret_cast<long long *>(s_best)[1];
@@ -539,7 +542,7 @@ hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, h
 template <int T>
 static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
 {
-    if (p.node_pat) hipLaunchKernelGGL((blk::sweep_blk_kernel<T, true>), dim3(grid), dim3(blk::THREADS), 0, s, p);     // ~100 KB of static LDS
+    if (p.node_code) hipLaunchKernelGGL((blk::sweep_blk_kernel<T, true>), dim3(grid), dim3(blk::THREADS), 0, s, p);     // ~100 KB of static LDS
     else hipLaunchKernelGGL((blk::sweep_blk_kernel<T, false>), dim3(grid), dim3(blk::THREADS), 0, s, p);
     return hipGetLastError();
 }

@@ -26,7 +26,6 @@ static constexpr int COOP_THREADS = 1024;  // 16 waves per CU: the fused update 
 static constexpr int COOP_MAXWORDS = 16;
 static constexpr int COOP_MB = GJ_MB;
 
-__device__ __forceinline__ int coop_sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
 
 __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p, int mb)
 {
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
     } else {
         for (int i = tid; i < n; i += COOP_THREADS) { s_basic[i] = flagbuf[i]; s_blocked[i] = 0; }
     }
-    const uint64_t pat = p.node_pat[0], gfree = p.node_free[0], gzero = p.node_zero[0];
+    const int8_t *code = p.node_code;                              // one node: per-variable constraint codes
     __threadfence();
     grid.sync();
     __threadfence();
@@ -76,10 +75,10 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             bool bad = false;
             if (v < n) {
                 const double q = __builtin_nontemporal_load(&T[(size_t)n * ld + v]);
-                const uint64_t vm = p.mask[v];
-                const int f = (vm & gzero) ? 0 : coop_sign_of_var(vm, pat);
+                const int cd = (int)code[v];
+                const int f = cd == 2 ? 0 : cd;
                 const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
-                if (vm & gfree) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);
+                if (cd == 2) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);
                 else if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
                 else bad = (fq > p.tol) && !s_blocked[v];
             }
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             p.node_sol[i] = s_basic[i] ? __builtin_nontemporal_load(&T[(size_t)n * ld + i]) : 0.0;
         if (tid == 0) {
             p.node_obj2[0] = __builtin_nontemporal_load(&T[(size_t)n * ld + n]);
-            p.best_obj[0] = 0.0; p.best_pat[0] = (int64_t)pat;
+            p.best_obj[0] = 0.0; p.best_pat[0] = 0;
             if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
             if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
         }

@@ -65,8 +65,8 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
 
         for (int64_t g = g0; g < g1; ++g) {
             uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
-            uint64_t gfree = 0, gzero = 0;
-            if (p.node_pat) { pat = p.node_pat[chain]; gfree = p.node_free[chain]; gzero = p.node_zero[chain]; }
+            const int8_t *code = p.node_code ? p.node_code + (size_t)chain * p.node_ld : nullptr;     // node mode: per-variable codes
+            if (code) pat = (uint64_t)chain;
             for (int i = tid; i < n; i += GEN_THREADS) s_blocked[i] = 0;
             __syncthreads();
             int ninf_best = n + 1, patience = 3, rounds = 0;
@@ -83,10 +83,10 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                     bool bad = false;
                     if (v < n) {
                         const double q = T[(size_t)n * ld + v];
-                        const uint64_t vm = p.mask[v];
-                        const int f = (vm & gzero) ? 0 : sign_of_var(vm, pat);
+                        const int cd = code ? (int)code[v] : 0;
+                        const int f = code ? (cd == 2 ? 0 : cd) : sign_of_var(p.mask[v], pat);
                         const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
-                        if (vm & gfree) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);   // free: stationarity only
+                        if (cd == 2) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);     // free: stationarity only
                         else if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
                         else bad = (fq > p.tol) && !s_blocked[v];
                     }

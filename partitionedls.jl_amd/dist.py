@@ -1,4 +1,5 @@
-"""Multi-GPU plumbing of the Opt sweep: shard the Gray-index space, then pick the global optimum with two tiny all-reduces.
+"""Multi-GPU plumbing: the Opt sweep shards the Gray-index space and picks the global optimum with two tiny all-reduces; the BnB
+search shards every frontier batch and shares bounds (hence the incumbent) with one all-gather per batch.
 
 One process per GPU; torch.distributed is only the transport (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU
 tests).  The reduction mirrors `argmin` at Opt.jl:96 — first minimal index on ties — as a lexicographic minimum over
@@ -25,3 +26,64 @@ def allreduce_argmin(obj, pat, device=None, group=None):
     dist.all_reduce(i, op=dist.ReduceOp.MIN, group=group)
     gpat = int(i[0])
     return gmin, (gpat if gpat != NO_CANDIDATE else -1)
+
+
+def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, device=None):
+    """fit_BnB (BnB.jl:94-132) as a best-first search whose frontier batches are sharded across ranks.
+
+    Every rank holds the SAME frontier (it is rebuilt from shared data only, so it never has to be exchanged): per round the
+    `batch * world` most promising nodes are popped, rank r bounds the nodes r, r + world, ... on its own GPU with
+    `bound_fn(pats, frees) -> (lb, branch)` (Context.bnb_bound), one all-gather shares the (bound, branch) pairs — which carries
+    the incumbent, the min over the feasible bounds — and every rank applies the same pruning and branching.  Returns
+    (mu, best_pat, best_free, nodes_bounded); the caller builds the model of that node locally (Context.bnb_leaf), as every
+    rank re-solves the winner after the Opt sweep.  A node is (pat, free): bit k of free set = group k not branched yet.
+    """
+    import heapq
+    import numpy as np
+    frontier = [(0.0, 0, 0, (1 << n_groups) - 1)]               # (parent bound, sequence number, pat, free): root = all free
+    seq = 1
+    mu, best = float("inf"), None
+    bounded = 0
+    use_dist = world > 1
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+    while frontier:
+        nodes = []
+        while frontier and len(nodes) < batch * world:
+            key, _, pat, free = heapq.heappop(frontier)
+            if key >= mu:
+                continue                                         # its bound can only be >= the parent's (BnB.jl:102)
+            nodes.append((pat, free))
+        if not nodes:
+            break
+        mine = nodes[rank::world]
+        lb_l, br_l = bound_fn(np.array([p for p, _ in mine], dtype=np.uint64), np.array([f for _, f in mine], dtype=np.uint64))
+        if use_dist:
+            per = (len(nodes) + world - 1) // world              # equal-sized slots so that one all_gather fits every rank
+            buf = torch.full((2 * per,), float("nan"), dtype=torch.float64, device=device)
+            buf[:len(mine)] = torch.as_tensor(np.asarray(lb_l, dtype=np.float64))
+            buf[per:per + len(mine)] = torch.as_tensor(np.asarray(br_l, dtype=np.float64))
+            out = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(out, buf, group=group)
+            lb = np.empty(len(nodes)); br = np.empty(len(nodes), dtype=np.int64)
+            for r in range(world):
+                cnt = len(nodes[r::world])
+                o = out[r].cpu().numpy()
+                lb[r::world] = o[:cnt]
+                br[r::world] = o[per:per + cnt].astype(np.int64)
+        else:
+            lb, br = np.asarray(lb_l, dtype=np.float64), np.asarray(br_l, dtype=np.int64)
+        for (pat, free), l, k in zip(nodes, lb, br):
+            bounded += 1
+            if l >= mu:
+                continue
+            if k < 0:                                            # feasible for the original problem (BnB.jl:109-115)
+                mu, best = float(l), (pat, free)
+                continue
+            bit = 1 << int(k)
+            heapq.heappush(frontier, (float(l), seq, pat | bit, free & ~bit)); seq += 1     # alpha_pk >= 0 first (BnB.jl:120,123)
+            heapq.heappush(frontier, (float(l), seq, pat & ~bit, free & ~bit)); seq += 1    # alpha_pk <= 0
+    if best is None:
+        raise RuntimeError("bnb_search: no feasible leaf found")
+    return mu, best[0], best[1], bounded

@@ -56,3 +56,83 @@ def test_allreduce_argmin_gloo_world2(partls):
         assert p.exitcode == 0
     for r in range(2):
         assert [tuple(x) for x in out[r]] == expect
+
+
+# ---- BnB: frontier batches sharded across ranks (dist.bnb_search); the bound function here is the CPU oracle's NNLS -----------
+def _bnb_problem():
+    import numpy as np
+    rng = np.random.default_rng(77)
+    N, D, K = 60, 12, 4
+    X = rng.standard_normal((N, D))
+    y = rng.standard_normal(N)                                  # no signal: the relaxation is rarely feasible, the search branches
+    P = np.zeros((D, K), dtype=np.int64)
+    P[np.arange(D), np.arange(D) % K] = 1
+    return X, y, P
+
+
+def _oracle_bound_fn(X, y, P):
+    """(pats, frees) -> (lb, branch): BnB.jl:69-92,107,117 restated with the oracle's dense NNLS on [Xp Xm]."""
+    import numpy as np
+    from oracle import oracle as O
+    N, M = X.shape
+    K = P.shape[1]
+    Xo = np.column_stack([X, np.ones(N)])
+    groups = [np.nonzero(P[:, k])[0] for k in range(K)] + [np.array([M])]
+
+    def bound(pats, frees):
+        lbs, brs = [], []
+        for pat, free in zip(pats.tolist(), frees.tolist()):
+            cols, owner, sign = [], [], []
+            state = np.zeros(M + 1, dtype=int)                    # bit 0: alpha >= 0 present, bit 1: alpha <= 0 present
+            for k, g in enumerate(groups):
+                if not (free >> k) & 1:
+                    state[g] |= 1 if (pat >> k) & 1 else 2
+            for m in range(M + 1):
+                if not state[m] & 2:
+                    cols.append(Xo[:, m]); owner.append(m); sign.append(1.0)
+                if not state[m] & 1:
+                    cols.append(-Xo[:, m]); owner.append(m); sign.append(-1.0)
+            A = np.column_stack(cols) if cols else np.zeros((N, 1))
+            x, rn, mode, _ = O.nnls(A, y)
+            w = np.zeros(M + 1)
+            for xi, m, sg in zip(x, owner, sign):
+                w[m] += sg * xi
+            nu = [float(np.clip(w[g], 0, None).sum() * np.clip(-w[g], 0, None).sum()) if (free >> k) & 1 else 0.0
+                  for k, g in enumerate(groups)]
+            kb = int(np.argmax(nu))
+            lbs.append(rn); brs.append(kb if nu[kb] > 0 else -1)
+        return np.array(lbs), np.array(brs, dtype=np.int32)
+    return bound
+
+
+def _bnb_worker(rank, world, port, out):
+    import torch.distributed as dist
+    import partls_amd
+    pls = partls_amd.package()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    X, y, P = _bnb_problem()
+    out[rank] = pls.dist.bnb_search(_oracle_bound_fn(X, y, P), P.shape[1] + 1, rank=rank, world=world, batch=4)
+    dist.destroy_process_group()
+
+
+def test_bnb_search_sharded_gloo_world2(partls, oracle):
+    """2 ranks (frontier batches dealt round-robin, one all-gather per batch) == 1 rank == the oracle's depth-first fit_BnB."""
+    import torch.multiprocessing as mp
+    X, y, P = _bnb_problem()
+    single = partls.dist.bnb_search(_oracle_bound_fn(X, y, P), P.shape[1] + 1, batch=4)
+    ref = oracle.fit_bnb(X, y, P)
+    assert abs(single[0] - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+    assert single[3] > 8                                         # the instance really branches
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_bnb_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(2):
+        mu, pat, free, bounded = out[r]
+        assert (pat, free) == (single[1], single[2]) and abs(mu - single[0]) <= 1e-12 * max(1.0, single[0])
+    assert out[0][3] == out[1][3]                                # replicated frontier: identical node counts on both ranks

@@ -110,23 +110,3 @@ def test_c5_bnb_equals_opt(partls):
     np.testing.assert_allclose(ab, ao, atol=1e-7)
     np.testing.assert_allclose(bb, bo_, atol=1e-7)
     assert nopen < (1 << K) // 64                             # the bound prunes: far fewer nodes than patterns
-
-
-def test_c4_shape_alt(partls):
-    """BASELINE config 4 shape, rows reduced 4x to keep the test short (N=250k, D=512, K=16): Alt from a random start on
-    the n = 513 tableau (global-memory kernel) reaches the noise floor; every iterate is a valid model."""
-    seed, N, D, K = 20260004, 250_000, 512, 16
-    ctx, dX, dy, P, ws = _device_problem(partls, seed, N, D, K)
-    ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
-    rng = np.random.default_rng(123)
-    a0 = rng.random(D + 1); b0 = (rng.random(K + 1) - 0.5) * 10
-    a, b, t, opt, iters = ctx.alt_prepared(a0, b0, eps=1e-6, T=200)
-    assert 1 <= iters <= 200 and np.all(a >= 0)
-    grp = np.argmax(P, axis=1)
-    for k in range(K):
-        assert abs(a[grp == k].sum() - 1.0) < 1e-9            # alpha normalised per group (Alt.jl:95-98)
-    G = ctx.gram()
-    w = np.concatenate([a * b[grp], [t]])
-    obj = np.sqrt(w @ G[:D + 1, :D + 1] @ w - 2 * w @ G[:D + 1, D + 1] + G[D + 1, D + 1])
-    assert abs(obj - opt) <= 1e-8 * opt
-    assert opt < 1.5 * 0.1 * np.sqrt(N)                       # Alt is a local method; it gets close to the noise floor here
