@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — sign-pattern NNLS solves/sec of fit(Opt) on the BASELINE.json headline config, on N GPUs of one node.
+"""bench.py — the hot path of PartitionedLS on MI355X, one BASELINE.json config per run (default C3, the headline).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config C2|C3|C4|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over the synthetic problem, inputs resident in HBM when the timed region starts:
-Gram build (fp64 MFMA) -> tableau prep -> sign-pattern sweep over this rank's shard of the Gray-index space ->
-all-reduce(min objective, then min index among the minimisers) over RCCL -> winner re-solve + objective from the data.
-The 2^K' patterns of ONE problem are sharded across ranks (total work fixed => "strong" scaling); there is no data-path
-collective besides the two 8-byte all-reduces.  value = patterns solved by all ranks / max-over-ranks time.
-
-Rank 0 prints ONE JSON line (see README/DESIGN.md §6 for the roofline and cpu_baseline definitions).
+One "step" = one pass of the hot path over the synthetic problem, inputs resident in HBM when the timed region starts.
+  C2 / C3 (fit(Opt)): Gram build (fp64 MFMA) -> tableau prep -> sign-pattern sweep over this rank's shard of the Gray-index space
+        -> all-reduce(min objective, then min index among the minimisers) over RCCL -> winner re-solve + objective from the data.
+        The 2^K' patterns of ONE problem are sharded across ranks (total work fixed => "strong" scaling); no data-path collective
+        besides the two 8-byte all-reduces.  value = patterns solved by all ranks / max-over-ranks time.
+  C5 (fit(BnB), K = 24): the same Opt enumeration of 2^24 patterns (value, as above) followed by fit(BnB) with the frontier
+        batches sharded across the ranks (dist.bnb_search: one all-gather of (bound, branch) per batch); BnB time and node
+        count ride in `bnb`.  `bnb_hard` (rank 0, once, outside the timed region): the same search on a pure-noise target,
+        where the relaxation is never feasible at the root, capped at --bnb-cap nodes: nodes bounded per second.
+  C4 (fit(Alt), N = 1M, D = 512): Gram build + the ALS loop (T = 200, eps = 1e-6 as Alt.jl:50-51; it converges long before T).
+        One GPU per north_star: with N ranks every rank fits its own replica ("weak": replicas only, no collective).
+        value = fits/s over all ranks; the roofline object is the Gram kernel's fp64-MFMA fraction.
+Rank 0 prints ONE JSON line (DESIGN.md §6 defines `roofline`, `roofline_fp64` and `cpu_baseline`).
 """
 import argparse
 import json
@@ -22,12 +28,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (seed, N, D, K)   — BASELINE.md §4
-    "C2": (20260002, 10_000, 128, 12),
-    "C3": (20260003, 100_000, 256, 20),
+    # name: (kind, seed, N, D, K)   — BASELINE.md §4
+    "C2": ("opt", 20260002, 10_000, 128, 12),
+    "C3": ("opt", 20260003, 100_000, 256, 20),
+    "C4": ("alt", 20260004, 1_000_000, 512, 16),
+    "C5": ("bnb", 20260005, 100_000, 256, 24),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # public datasheet (vector = matrix fp64 on MI355X); not in the on-image guides
+METRIC = "sign-pattern NNLS solves/sec (whole node); fp64 obj gap vs ref"
 
 
 def algorithmic_bytes_per_solve(Mp):
@@ -43,7 +52,9 @@ def main():
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
     ap.add_argument("--faithful", action="store_true", help="enumerate the reference's 2^(K+1) patterns (intercept sign too)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-patterns", type=int, default=0, help="patterns in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--cpu-patterns", type=int, default=32, help="patterns in the dense CPU baseline sample")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baselines (0 = min(16, cores))")
+    ap.add_argument("--bnb-cap", type=int, default=20000, help="node cap of the C5 bnb_hard leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,26 +86,50 @@ def main():
     L = pls.lowlevel
     ctx = pls.Context(dev_index)
 
-    seed, N, D, K = CONFIGS[args.config]
+    kind, seed, N, D, K = CONFIGS[args.config]
     P, wstar = pls.synth_truth(seed, D, K)
     dX = torch.empty(N * D, dtype=torch.float64, device=dev)         # column-major N x D, resident in HBM
     dy = torch.empty(N, dtype=torch.float64, device=dev)
     ctx.synth_device(seed, N, D, wstar, dX.data_ptr(), dy.data_ptr())
     torch.cuda.synchronize()
     flags = L.OPT_FAITHFUL_INTERCEPT if args.faithful else 0
+    rng0 = np.random.default_rng(123)
+    alt_a0, alt_b0 = rng0.random(D + 1), (rng0.random(K + 1) - 0.5) * 10    # the start Alt.jl:65-66 would draw
 
-    def step():
+    def opt_pass():
         ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, flags)
         npat = ctx.num_patterns()
         g0, g1 = pls.dist.shard_range(npat, rank, world)
         bobj, bpat, _, unconv = ctx.opt_sweep(g0, g1)
         t_gram, t_prep, t_sweep = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP)
-        pivots = ctx.pivots()
+        pivots, vetoes = ctx.pivots(), ctx.vetoes()
         # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
         _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=red_dev)
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         return dict(npat=npat, local=g1 - g0, opt=opt, best_index=bi, unconv=unconv, t_gram=t_gram, t_prep=t_prep,
-                    t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), alpha=a, beta=b, t=t, pivots=pivots)
+                    t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), pivots=pivots, vetoes=vetoes)
+
+    def bnb_pass(cap=None):
+        ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
+        t0 = time.perf_counter()
+        mu, pat, free, bounded = pls.dist.bnb_search(ctx.bnb_bound, K + 1, rank=rank, world=world, device=red_dev, max_nodes=cap)
+        a, b, t, opt = ctx.bnb_leaf(pat, free)
+        return dict(opt=opt, nopen=bounded, seconds=time.perf_counter() - t0)
+
+    def alt_pass():
+        ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
+        t_gram, t_prep = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP)
+        t0 = time.perf_counter()
+        a, b, t, opt, iters = ctx.alt_prepared(alt_a0, alt_b0, eps=1e-6, T=200)
+        return dict(opt=opt, iters=iters, t_gram=t_gram, t_prep=t_prep, alt_ms=(time.perf_counter() - t0) * 1e3)
+
+    def step():
+        if kind == "alt":
+            return alt_pass()
+        r = opt_pass()
+        if kind == "bnb":
+            r["bnb"] = bnb_pass()
+        return r
 
     def barrier():
         if world > 1:
@@ -105,83 +140,121 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    sweep_ms, gram_ms = [], []
-    res = None
+    hist = []
     for _ in range(args.steps):
-        res = step()
-        sweep_ms.append(res["t_sweep"])
-        gram_ms.append(res["t_gram"])
+        hist.append(step())
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-
-    npat = res["npat"]
-    value = npat * args.steps / elapsed
+    res = hist[-1]
+    avg = lambda key: sum(h[key] for h in hist) / len(hist)
     Mp = D + 1
-    # dominant kernel = the sweep; its launch processes this rank's shard; duration from HIP events on the library's stream
-    sweep_avg_s = (sum(sweep_ms) / len(sweep_ms)) * 1e-3
-    solves_per_launch = res["local"]
-    bytes_per_solve = algorithmic_bytes_per_solve(Mp)
-    achieved_gbs = solves_per_launch * bytes_per_solve / sweep_avg_s / 1e9
-    # fp64 view of the same kernel: every pivot is one rank-1 update of the symmetric tableau = T(T+1)/2 tile slots x 256 FMAs
-    n_tab = Mp if args.faithful else D
-    tiles = (n_tab + 15) // 16
-    flops = res["pivots"] * (tiles * (tiles + 1) // 2) * 256 * 2
-    fp64_tflops = flops / sweep_avg_s / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_sweep_traffic.json")
-    if world == 1 and args.config == "C3" and not args.faithful and os.path.exists(tpath):
-        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]       # rocprofv3 PMC, measured offline on this kernel
-    out = {
-        "metric": "sign-pattern NNLS solves/sec (whole node); fp64 obj gap vs ref",
-        "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.config}: fit(Opt) N={N} D={D} K={K}, {npat} sign patterns "
-                               f"({'2^(K+1) faithful' if args.faithful else '2^K, free intercept'}), eta=0",
-                   "seed": seed, "sharding": f"gray-index range / {world} ranks"},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3,
-                     "algorithmic_bytes_per_solve": bytes_per_solve, "solves_per_launch": solves_per_launch},
-        "roofline_fp64": {"bound": "fp64 vector FMA", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": fp64_tflops / FP64_PEAK_TFLOPS, "pivots_per_launch": res["pivots"],
-                          "note": "the tableau is register-resident, so the kernel's real bound is fp64 FMA issue, not HBM"},
-        "kernels_ms": {"gram_build": sum(gram_ms) / len(gram_ms), "prep": res["t_prep"], "sweep": sweep_avg_s * 1e3,
-                       "finish": res["t_finish"]},
-        "result": {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"]},
-    }
+    out = {"metric": METRIC, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic"}
+    gram_flops = 2.0 * N * (D + 2) ** 2 / 2                      # useful flops of the SYRK-shaped Gram build (upper triangle)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if kind in ("opt", "bnb"):
+        npat = res["npat"]
+        out["value"] = npat * args.steps / elapsed
+        out["scaling"] = "strong"
+        out["config"] = {"workload": f"{args.config}: fit({'Opt' if kind == 'opt' else 'Opt enumeration + BnB'}) N={N} D={D} K={K}, "
+                                     f"{npat} sign patterns ({'2^(K+1) faithful' if args.faithful else '2^K, free intercept'}), eta=0",
+                         "seed": seed, "sharding": f"gray-index range / {world} ranks"}
+        # dominant kernel = the sweep; its launch processes this rank's shard; duration from HIP events on the library's stream
+        sweep_avg_s = avg("t_sweep") * 1e-3
+        solves_per_launch = res["local"]
+        bytes_per_solve = algorithmic_bytes_per_solve(Mp)
+        achieved_gbs = solves_per_launch * bytes_per_solve / sweep_avg_s / 1e9
+        # fp64 view of the same kernel: every pivot is one rank-1 update of the symmetric tableau = T(T+1)/2 tile slots x 256 FMAs
+        n_tab = Mp if args.faithful else D
+        tiles = (n_tab + 15) // 16
+        flops = res["pivots"] * (tiles * (tiles + 1) // 2) * 256 * 2
+        fp64_tflops = flops / sweep_avg_s / 1e12
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_sweep_traffic.json")
+        if world == 1 and args.config == "C3" and not args.faithful and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            tsrc = "offline PMC (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this kernel, corrected per MI355X_MICROARCH.md), " \
+                   "profiles/r02_sweep_traffic.json — not measured in this run"
+        out["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                           "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3,
+                           "algorithmic_bytes_per_solve": bytes_per_solve, "solves_per_launch": solves_per_launch,
+                           "note": "SURVEY §8(d) nominal bytes; the tableau is register-resident, so HBM is idle — see roofline_fp64"}
+        out["roofline_fp64"] = {"bound": "fp64 vector FMA", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fp64_tflops / FP64_PEAK_TFLOPS, "pivots_per_launch": res["pivots"],
+                                "note": "the kernel's real bound: fp64 FMA issue of the rank-1 tableau updates"}
+        out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
+        out["gram"] = {"tflops_useful": gram_flops / (avg("t_gram") * 1e-3) / 1e12, "frac_of_fp64_mfma_peak":
+                       gram_flops / (avg("t_gram") * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        out["result"] = {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"], "loo_vetoes": res["vetoes"]}
+        if kind == "bnb":
+            out["bnb"] = {"seconds": sum(h["bnb"]["seconds"] for h in hist) / len(hist), "nodes_bounded": res["bnb"]["nopen"],
+                          "opt": res["bnb"]["opt"], "gap_vs_opt": abs(res["bnb"]["opt"] - res["opt"]) / res["opt"],
+                          "sharding": f"frontier batches of 512 x {world} nodes, one all-gather per batch"}
+    else:
+        out["metric"] = "fit(Alt) fits/sec (Gram build + ALS loop); Gram build fp64-MFMA fraction"
+        out["unit"] = "fits/s"
+        out["value"] = world * args.steps / elapsed
+        out["scaling"] = "weak"
+        out["config"] = {"workload": f"{args.config}: fit(Alt) N={N} D={D} K={K}, T=200, eps=1e-6, start drawn as Alt.jl:65-66 "
+                                     f"(numpy seed 123), eta=0", "seed": seed,
+                         "sharding": "replicas only: one GPU per fit (north_star), no collective"}
+        gram_s = avg("t_gram") * 1e-3
+        tf = gram_flops / gram_s / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                           "traffic": None, "traffic_source": None, "kernel": "gram_kernel", "kernel_ms": gram_s * 1e3,
+                           "algorithmic_flops": gram_flops, "note": "useful flops of the upper triangle of [X 1 y]'[X 1 y]"}
+        out["kernels_ms"] = {"gram_build": gram_s * 1e3, "prep": res["t_prep"], "alt_loop": avg("alt_ms")}
+        out["alt"] = {"iterations": res["iters"], "ms_per_iteration": avg("alt_ms") / max(1, res["iters"]), "opt": res["opt"],
+                      "noise_floor": 0.1 * N ** 0.5}
+
+    if rank == 0 and kind == "bnb":
+        # BnB where it has to branch: target = intercept + noise (no feature carries signal), same X, same shape
+        ctx.synth_device(seed, N, D, np.zeros(D), dX.data_ptr(), dy.data_ptr())
+        torch.cuda.synchronize()
+        ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
+        t1 = time.perf_counter()
+        mu, pat, free, bounded = pls.dist.bnb_search(ctx.bnb_bound, K + 1, max_nodes=args.bnb_cap)
+        dt = time.perf_counter() - t1
+        out["bnb_hard"] = {"target": "y = 1 + 0.1 * noise (wstar = 0)", "nodes_bounded": bounded, "seconds": dt,
+                           "nodes_per_s": bounded / dt, "capped": bounded >= args.bnb_cap,
+                           "incumbent": (mu if mu != float("inf") else None)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "alt":
         out["cpu_baseline"] = cpu_baseline(args, seed, N, D, K, res, np)
     if rank == 0:
         print(json.dumps(out))
+    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 
 
 def cpu_baseline(args, seed, N, D, K, res, np):
-    """The oracle in reference-faithful dense mode (Opt.jl:87-90 per pattern: column scaling + dense Lawson–Hanson on the
-    N x (D+1) matrix + objective), single-threaded like the reference, on a bounded sample of patterns that always
-    includes the GPU's winner (whose objective is compared: the fp64 objective gap)."""
-    from oracle import oracle as O
-    X, y, P, _ = O.synth(seed, N, D, K)
-    Xo, Po = O.homogeneous(X, P)
+    """A: the oracle in reference-faithful dense mode (Opt.jl:87-90 per pattern: column scaling + dense Lawson–Hanson on the
+    N x (D+1) matrix + objective) on a bounded sample that always includes the GPU's winner (whose objective is compared: the
+    fp64 objective gap).  B: the same NNLS on the QR-compressed problem — the CPU analogue of the Gram form — on 1 core and on
+    all workers.  Both run in spawned worker processes of oracle/cpu_baseline.py."""
+    from oracle import cpu_baseline as CB
+    workers = args.cpu_workers or CB.default_workers()
     npat_ref = 1 << (K + 1)
-    n = args.cpu_patterns or (3 if N * D > 5_000_000 else 24)
+    n = max(1, args.cpu_patterns)
     rng = np.random.default_rng(0)
     sample = [int(res["best_index"])] + [int(v) for v in rng.integers(0, npat_ref, size=n - 1)]
-    t0 = time.perf_counter()
-    objs = O.opt_patterns(Xo, y, Po, np.array(sample, dtype=np.int64))
-    dt = time.perf_counter() - t0
+    objs, wall, cpu_s, setup = CB.dense_sample(seed, N, D, K, sample, min(workers, n))
     gap = abs(objs[0] - res["opt"]) / max(1.0, objs[0])
-    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+    b1, bn, bsetup = CB.compressed_rates(seed, N, D, K, 64 if N * D > 5_000_000 else 256, workers)
+    return {"value": n / wall, "unit": "solves/s", "cores": min(workers, n), "kind": "port",
             "sample": f"{n} of {npat_ref} patterns (winner + random), dense Lawson-Hanson per pattern as Opt.jl:87-90, "
-                      f"C restatement of the reference algorithm (not Julia), host has {os.cpu_count()} cores",
-            "seconds": dt, "obj_gap_winner": gap, "oracle_opt_winner": float(objs[0])}
+                      f"C restatement of the reference algorithm (not Julia), one pattern per worker call; host has {os.cpu_count()} cores",
+            "seconds": wall, "per_core_solves_per_s": n / cpu_s, "obj_gap_winner": gap, "oracle_opt_winner": float(objs[0]),
+            "gram_form": {"what": "Baseline B (BASELINE.md §3.2): the same NNLS on the QR-compressed (D+2) x (D+1) problem, i.e. the "
+                                  "data are read once as on the GPU; compression time not included",
+                          "solves_per_s_1_core": b1, "solves_per_s_all_workers": bn, "workers": workers,
+                          "compress_seconds_1_core": bsetup}}
 
 
 if __name__ == "__main__":

@@ -216,6 +216,8 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         // one large problem: many workgroups cooperate on a single global-memory tableau (sweep_coop.hip)
         p.T0 = c->Tfull.as<double>();
         p.resume = (resume && c->coop_state_valid) ? 1 : 0;
+        PARTLS_HIP_CHECK(c->gridCtr.ensure(64));
+        p.grid_ctr = c->gridCtr.as<unsigned>();
         c->coop_state_valid = true;
         int nwg = (ld + 15) / 16;
         if (nwg > 64) nwg = 64;
@@ -436,7 +438,7 @@ void partls_destroy(partls_ctx *c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
-                          &c->flag, &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj,
+                          &c->flag, &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
                           &c->predX, &c->predY};
         for (DevBuf *b : bufs) b->release();
         for (int w = 0; w < PARTLS_T_COUNT; ++w) {

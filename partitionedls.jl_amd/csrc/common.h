@@ -54,6 +54,7 @@ struct SweepParams {
     // cooperative single-node kernel only: continue from the tableau / basis left in `scratch` by the previous launch
     // (warm start of consecutive Alt alpha-steps) instead of reloading T0
     int resume;
+    unsigned *grid_ctr;          // multi-workgroup kernel: arrival counter of its grid barrier (zeroed by the launcher)
 };
 
 // launchers (each returns hipError_t of the launch)

@@ -55,7 +55,7 @@ struct partls_ctx {
     // gram
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
-        wdev, partial, flag, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY;
+        wdev, partial, flag, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr;
     std::vector<double> hG, hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
     int n = 0, kbits = 0, T = 0;

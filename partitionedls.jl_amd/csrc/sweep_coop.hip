@@ -1,4 +1,4 @@
-// sweep_coop.hip — ONE large subproblem solved by many workgroups (cooperative launch, grid-wide barriers), BLOCKED pivots.
+// sweep_coop.hip — ONE large subproblem solved by many workgroups (grid-wide barriers), BLOCKED pivots.
 //
 // Used for single "node" solves whose tableau does not fit the register-resident kernel (n > 272): the α-step of
 // fit(Alt) at BASELINE config 4 (n = 513, Alt.jl:80-90) and the winner re-solve of fit(Opt) at such sizes.  Same
@@ -15,12 +15,38 @@
 //                the rows / columns of the pivoted variables from the final panel;
 //   4. one grid barrier (plus one between 1 and 3: the panel copies must be complete before any owner rewrites a pivot row).
 // So the grid synchronises twice per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables).
+//
+// Grid barrier.  An ordinary launch with a hand-written barrier on a monotone global counter (release add / acquire poll at
+// agent scope), not hipLaunchCooperativeKernel: the runtime's cooperative queue cost ~7 ms on its first use in a process and,
+// under rocprofv3, crashed the process inside exit() after the tool had finalised (round-1 finding, reproduced in round 2 with
+// every context closed and every buffer freed: profiles/README.md).  What the cooperative launch guaranteed — that all
+// workgroups are resident at once, so that nobody spins on a workgroup that cannot start — is ensured by the host instead:
+// the grid is capped at (compute units) x (resident workgroups per CU from the occupancy query), far above the <= 64 used.
 #include "gj_panel.h"
-#include <hip/hip_cooperative_groups.h>
-
-namespace cg = cooperative_groups;
 
 namespace partls {
+
+// All threads of all workgroups call it the same number of times.  `epoch` counts arrivals expected so far (this workgroup's
+// private copy); the counter is zeroed by the host before the launch and never reset inside the kernel.  The spin is bounded
+// (cdna_hip_programming.md §1): a workgroup that waits ~4 s gives up, returns false to all its threads, and the kernel exits
+// with n_unconverged poisoned so that the host reports an error instead of hanging the device.
+__device__ __forceinline__ bool grid_barrier(unsigned *ctr, unsigned nwg, unsigned &epoch, int *s_ok)
+{
+    __syncthreads();                                               // every wave's stores are issued ...
+    if (threadIdx.x == 0) {
+        epoch += nwg;
+        __threadfence();                                           // ... and visible at agent scope before the arrival
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 26)) { *s_ok = 0; break; }
+        }
+        __threadfence();                                           // acquire: drops this CU's stale L1 lines
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
 
 static constexpr int COOP_THREADS = 1024;  // 16 waves per CU: the fused update is bound by memory latency, not by issue
 static constexpr int COOP_MAXWORDS = 16;
@@ -29,7 +55,7 @@ static constexpr int COOP_MB = GJ_MB;
 
 __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p, int mb)
 {
-    cg::grid_group grid = cg::this_grid();
+    unsigned epoch = 0;                                            // grid-barrier arrivals expected so far
     const int n = p.n, ld = n + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     extern __shared__ double smem[];
@@ -43,6 +69,8 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
     __shared__ unsigned long long s_inf[COOP_MAXWORDS];
     __shared__ int s_viol[COOP_MAXWORDS * 64];
     __shared__ int s_nv;
+    __shared__ int s_ok;                                           // 0 after a grid-barrier timeout
+    if (threadIdx.x == 0) s_ok = 1;
 
     double *T = p.scratch;
     const int nwg = gridDim.x, wg = blockIdx.x;
@@ -59,9 +87,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
         for (int i = tid; i < n; i += COOP_THREADS) { s_basic[i] = flagbuf[i]; s_blocked[i] = 0; }
     }
     const int8_t *code = p.node_code;                              // one node: per-variable constraint codes
-    __threadfence();
-    grid.sync();
-    __threadfence();
+    if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
 
     unsigned long long npiv = 0, nunconv = 0;
     int ninf_best = n + 1, patience = 3, rounds = 0;
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             gj_panel_load<COOP_THREADS>(T, ld, ks, m, Pn, tid);
             // every workgroup has its copy of the pivot rows (and has finished the KKT scan of the rhs row) before any owner
             // rewrites them: without this barrier a fast workgroup's update races with a slow one's panel load
-            grid.sync();
+            if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
             gj_panel_eliminate<COOP_THREADS>(Pn, Zn, dinv, uj, red, ks, m, ld, s_basic, p.piv_eps, tid);
             gj_apply<COOP_THREADS>(T, ld, row0, row1, Pn, Zn, dinv, ks, m, tid);
             if (tid == 0) {
@@ -123,9 +149,8 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
                 }
             }
             for (int j = 0; j < m; ++j) if (dinv[j] != 0.0) { progress = true; ++npiv; }
-            __threadfence();
-            grid.sync();                                   // the whole tableau is updated before anybody reads it again
-            __threadfence();                               // agent-scope acquire on this CU (per-XCD L2s are not coherent)
+            // the whole tableau is updated before anybody reads it again (agent-scope release / acquire inside: per-XCD L2s are not coherent)
+            if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
         }
     }
     if (wg == 0) {
@@ -150,10 +175,17 @@ hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_coop_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
-    SweepParams pc = p;
-    void *args[] = {&pc, &mb};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&sweep_coop_kernel), dim3(nwg), dim3(COOP_THREADS), args,
-                                      (unsigned)shmem, s);
+    // the hand-written grid barrier needs every workgroup resident at the same time: cap the grid by what the device can hold
+    int dev = 0, ncu = 0, per_cu = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&sweep_coop_kernel), COOP_THREADS, shmem)) != hipSuccess) return e;
+    const long long resident = (long long)ncu * per_cu;
+    if (resident < 1) return hipErrorLaunchOutOfResources;
+    if (nwg > resident) nwg = (int)resident;
+    if ((e = hipMemsetAsync(p.grid_ctr, 0, 16, s)) != hipSuccess) return e;      // the polled word, in a 16-byte block of its own
+    hipLaunchKernelGGL(sweep_coop_kernel, dim3(nwg), dim3(COOP_THREADS), shmem, s, p, mb);
+    return hipGetLastError();
 }
 
 }  // namespace partls

@@ -28,7 +28,7 @@ def allreduce_argmin(obj, pat, device=None, group=None):
     return gmin, (gpat if gpat != NO_CANDIDATE else -1)
 
 
-def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, device=None):
+def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, device=None, max_nodes=None):
     """fit_BnB (BnB.jl:94-132) as a best-first search whose frontier batches are sharded across ranks.
 
     Every rank holds the SAME frontier (it is rebuilt from shared data only, so it never has to be exchanged): per round the
@@ -37,6 +37,7 @@ def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, devic
     the incumbent, the min over the feasible bounds — and every rank applies the same pruning and branching.  Returns
     (mu, best_pat, best_free, nodes_bounded); the caller builds the model of that node locally (Context.bnb_leaf), as every
     rank re-solves the winner after the Opt sweep.  A node is (pat, free): bit k of free set = group k not branched yet.
+    max_nodes (measurement only): stop after that many bounded nodes and return the incumbent so far (inf if none yet).
     """
     import heapq
     import numpy as np
@@ -49,6 +50,8 @@ def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, devic
         import torch
         import torch.distributed as dist
     while frontier:
+        if max_nodes is not None and bounded >= max_nodes:
+            break
         nodes = []
         while frontier and len(nodes) < batch * world:
             key, _, pat, free = heapq.heappop(frontier)
@@ -85,5 +88,7 @@ def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, devic
             heapq.heappush(frontier, (float(l), seq, pat | bit, free & ~bit)); seq += 1     # alpha_pk >= 0 first (BnB.jl:120,123)
             heapq.heappush(frontier, (float(l), seq, pat & ~bit, free & ~bit)); seq += 1    # alpha_pk <= 0
     if best is None:
+        if max_nodes is not None:
+            return mu, 0, (1 << n_groups) - 1, bounded
         raise RuntimeError("bnb_search: no feasible leaf found")
     return mu, best[0], best[1], bounded

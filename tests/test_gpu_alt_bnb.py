@@ -94,13 +94,17 @@ def test_non_contiguous_partition_is_permuted_correctly(partls):
     np.testing.assert_allclose(model.α, g["opt_alpha"], atol=1e-7)
 
 
-def test_overlapping_partition_rejected_for_alt_bnb(partls):
-    X = np.random.default_rng(0).standard_normal((50, 4)); y = X[:, 0] + 1
+def test_overlapping_partition_accepted_for_alt_bnb(partls, oracle):
+    """any 0/1 P is valid input (PartitionedLS.jl:292); round 1 rejected overlapping groups for Alt / BnB — now they run on the
+    device with per-variable node codes and agree with the oracle (more cases: test_gpu_configs.py)"""
+    X = np.random.default_rng(0).standard_normal((50, 4)); y = X[:, 0] - 0.5 * X[:, 2] + 1
     P = np.array([[1, 0], [1, 1], [0, 1], [0, 1]])
-    for alg in (partls.Alt, partls.BnB):
-        with pytest.raises(partls.PartlsError) as ei:
-            partls.fit(alg, X, y, P, alpha0=np.ones(5), beta0=np.ones(3))
-        assert ei.value.status == partls.lowlevel.ERR_UNSUPPORTED
+    ref = oracle.fit_alt(X, y, P, np.ones(5), np.ones(3), eps=1e-6, T=100)
+    m, _, rep = partls.fit(partls.Alt, X, y, P, alpha0=np.ones(5), beta0=np.ones(3))
+    assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
+    rb = oracle.fit_bnb(X, y, P)
+    m2, _, rep2 = partls.fit(partls.BnB, X, y, P)
+    assert abs(rep2.opt - rb["opt"]) <= 1e-8 * max(1.0, rb["opt"])
 
 
 def test_alt_and_opt_beyond_register_kernel(partls, oracle):

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import partls_amd
 pls = partls_amd.package(); L = pls.lowlevel
-ctx = pls.Context(0)
+ctx = pls.Context(0)          # module global ON PURPOSE: round 1 crashed in exit() with this + the profiler (api.py atexit hook)
 
 def problem(seed, N, D, K):
     P, ws = pls.synth_truth(seed, D, K)
@@ -40,3 +40,11 @@ out["C4_alt_200_iterations"] = dict(alt_s=t4 - t3, iters=iters2, ms_per_iteratio
 out["C4_alt"] = dict(prepare_s=t1 - t0, gram_ms=gram_ms, gram_tflops_useful=flops / (gram_ms * 1e-3) / 1e12, alt_s=t2 - t1, iters=iters, opt=opt,
                      noise_floor=0.1 * np.sqrt(N))
 print(json.dumps(out, indent=1))
+# teardown experiments for the exit-time crash under rocprofv3 (profiles/README.md): FS_MODE=close closes the context explicitly,
+# FS_MODE=free additionally drops the torch tensors and the caching allocator's blocks before the interpreter exits
+mode = os.environ.get("FS_MODE", "")
+if mode in ("close", "free"):
+    ctx.close()
+if mode == "free":
+    del dX, dy
+    torch.cuda.empty_cache()
