@@ -6,8 +6,8 @@
 // c = Xo'y is column M+1, yy = y'y the corner; the ones column and y are virtual (never materialised).
 //
 // Kernel: 64x64 output macro-tile per workgroup (4 waves, each 16 rows x 64 cols = 4 v_mfma_f64_16x16x4_f64
-// accumulators), samples split into row chunks across blockIdx.y, each chunk staged through LDS in 32-sample panels
-// ([col][34] layout: conflict-free for the ds_read_b64 fragment reads).  Only tile pairs I <= J are computed (SYRK).
+// accumulators, + 1 on diagonal tiles for the ones / y columns), samples split into row chunks, each chunk staged through LDS
+// in 32-sample panels ([col][34] layout: conflict-free for the ds_read_b64 fragment reads).  Only tile pairs I <= J (SYRK).
 // Partial tiles go to a per-chunk slab and are summed in a fixed order by gram_reduce (bitwise reproducible;
 // no float atomics).  Roofline: fp64 MFMA bound — 2*N*(M+2)^2/2 flops over 8*N*M bytes (intensity ~ M/8 flop/B).
 #include "common.h"
@@ -21,10 +21,15 @@ static constexpr int GT = 64;      // macro tile edge
 static constexpr int GK = 32;      // samples per LDS panel
 static constexpr int GLD = 34;     // padded panel stride (doubles): bank = (4c + 2s) % 64, distinct per 32-lane group
 
-// Loading one element of Z = [X 1 y] is split in two so that the global loads stay in flight under the MFMAs:
+// Tiles cover the FEATURES only (nt = ceil(M / 64) tile columns, pairs I <= J).  The two virtual columns of Z = [X 1 y] — the
+// ones column and y — would cost a whole 64-wide tile column for two columns (9 of 45 tiles at D = 512); instead they ride on
+// the DIAGONAL tiles: tile (I, I) carries a fifth 16 x 16 accumulator whose B fragment is [1, y, 0, ...], which yields
+// X_I' 1 and X_I' y for its 64 columns at a quarter of a tile's cost, and the workgroups of tile (0, 0) also accumulate the
+// 2 x 2 corner (N, 1'y, y'y) as plain sums.
+//
+// Loading one feature element is split in two so that the global loads stay in flight under the MFMAs:
 //   z_load  : unconditional load from a clamped address (issued one panel ahead, result untouched),
-//   z_value : the selects for the virtual columns (ones / y / padding; only tiles that reach column M, EDGE) and the row
-//             tail, applied when the panel is written to LDS.
+//   z_value : zero for the padding columns of the last tile (EDGE) and for the row tail, applied at the LDS store.
 template <bool EDGE>
 __device__ __forceinline__ double z_load(const double *__restrict__ X, int64_t ldX, int M, int col, int64_t rr)
 {
@@ -32,10 +37,10 @@ __device__ __forceinline__ double z_load(const double *__restrict__ X, int64_t l
     return X[rr + (int64_t)cc * ldX];
 }
 template <bool EDGE>
-__device__ __forceinline__ double z_value(double x, double yv, bool rv, int M, int col)
+__device__ __forceinline__ double z_value(double x, bool rv, int M, int col)
 {
     double v = x;
-    if constexpr (EDGE) v = col < M ? x : (col == M ? 1.0 : (col == M + 1 ? yv : 0.0));
+    if constexpr (EDGE) v = col < M ? x : 0.0;
     return rv ? v : 0.0;
 }
 
@@ -44,38 +49,41 @@ __device__ __forceinline__ double z_value(double x, double yv, bool rv, int M, i
 // tile-pair workgroups of one (x, s) walk the SAME chunk sequence in step, so panels are re-read from that XCD's L2 by the
 // other tile pairs (speed only — correctness does not depend on placement).  Each workgroup accumulates all its chunks in
 // registers and writes one partial tile to slab (x*S + s).  Inside, the next 32-sample panel is prefetched into registers
-// (16 independent, unconditional global loads) while the MFMAs of the current one run from LDS.
-template <bool EA, bool EB>
+// (16 independent, unconditional global loads) while the MFMAs of the current one run from LDS, and the MFMA fragments of
+// k-step ks+1 are read from LDS before the MFMAs of k-step ks are issued (register double buffer).
+template <bool EA, bool EB, bool DIAG>
 __device__ __forceinline__ void gram_body(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
                                           const double *__restrict__ y, double *__restrict__ slab, int ldg,
-                                          int chunk_rows, int S, int I, int J, int xg, int sl, double *sA, double *sB)
+                                          int chunk_rows, int S, int I, int J, int xg, int sl, double *sA, double *sB, double *sV)
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double4_t acc[4];
+    double4_t acc[4], accv = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
     const int smp = lane & 31, csub = lane >> 5;       // loader: 32 lanes cover one column's 32 contiguous samples
     const int fr = lane & 15, fk = lane >> 4;          // MFMA fragment coordinates
-    const bool diag = (I == J);
-    const double *pB = diag ? sA : sB;
+    const double *pB = DIAG ? sA : sB;
     const int kb_per_chunk = chunk_rows / GK;
     const int64_t nchunks = (N + chunk_rows - 1) / chunk_rows;
     const int64_t cstride = (int64_t)8 * S;
+    const bool vloader = DIAG && tid < GK;             // threads 0..31 of a diagonal tile also stage [valid, y] of the panel
+    const bool corner = DIAG && I == 0 && tid < GK;    // ... and, for tile (0, 0), accumulate the 2 x 2 corner
+    double c11 = 0.0, c1y = 0.0, cyy = 0.0;
 
-    double va[8], vb[8], vy = 0.0;                     // raw prefetched values (+ y for the edge tile) and the row predicate
+    double va[8], vb[8], vy = 0.0;                     // raw prefetched values (+ y for the diagonal tiles) and the row predicate
     bool rv = false;
     auto fetch = [&](int64_t chunk, int kb) {
         const int64_t r1 = ((chunk + 1) * chunk_rows < N) ? (chunk + 1) * chunk_rows : N;
         const int64_t row = chunk * chunk_rows + (int64_t)kb * GK + smp;
         rv = row < r1;
         const int64_t rr = rv ? row : r1 - 1;
-        if constexpr (EA || EB) vy = y[rr];
+        if constexpr (DIAG) { if (vloader) vy = y[rr]; }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = i * 8 + wave * 2 + csub;
             va[i] = z_load<EA>(X, ldX, M, I * GT + c, rr);
-            vb[i] = z_load<EB>(X, ldX, M, J * GT + c, rr);                    // diagonal tiles: same lines, L1 hits
+            if constexpr (!DIAG) vb[i] = z_load<EB>(X, ldX, M, J * GT + c, rr);
         }
     };
 
@@ -87,22 +95,41 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ X, int64_t 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = i * 8 + wave * 2 + csub;
-            sA[c * GLD + smp] = z_value<EA>(va[i], vy, rv, M, I * GT + c);
-            sB[c * GLD + smp] = z_value<EB>(vb[i], vy, rv, M, J * GT + c);
+            sA[c * GLD + smp] = z_value<EA>(va[i], rv, M, I * GT + c);
+            if constexpr (!DIAG) sB[c * GLD + smp] = z_value<EB>(vb[i], rv, M, J * GT + c);
+        }
+        if constexpr (DIAG) {
+            if (vloader) {
+                const double one = rv ? 1.0 : 0.0, yv = rv ? vy : 0.0;
+                sV[smp] = one; sV[GK + smp] = yv;
+                if (corner) { c11 += one; c1y += yv; cyy = fma(yv, yv, cyy); }
+            }
         }
         __syncthreads();
         // advance and prefetch the next panel (global loads stay in flight under the MFMAs below)
         if (++kb == kb_per_chunk) { kb = 0; chunk += cstride; }
         have = chunk < nchunks && (chunk * chunk_rows + (int64_t)kb * GK) < N;
         if (have) fetch(chunk, kb);
+        // fragments: a = A[row wave*16 + fr][k = 4 ks + fk], b[jt] = B[col jt*16 + fr][k]; bv = [1, y, 0, ...][col fr][k]
+        double a_n = sA[(wave * 16 + fr) * GLD + fk], b_n[4], bv_n = 0.0;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) b_n[jt] = pB[(jt * 16 + fr) * GLD + fk];
+        if constexpr (DIAG) bv_n = fr < 2 ? sV[fr * GK + fk] : 0.0;
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
-            const double a = sA[(wave * 16 + fr) * GLD + ks * 4 + fk];
+            const double a = a_n, bv = bv_n;
+            double b[4];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const double b = pB[(jt * 16 + fr) * GLD + ks * 4 + fk];
-                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+            for (int jt = 0; jt < 4; ++jt) b[jt] = b_n[jt];
+            if (ks + 1 < GK / 4) {                     // next k-step's fragments are on their way while this one's MFMAs issue
+                a_n = sA[(wave * 16 + fr) * GLD + (ks + 1) * 4 + fk];
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) b_n[jt] = pB[(jt * 16 + fr) * GLD + (ks + 1) * 4 + fk];
+                if constexpr (DIAG) bv_n = fr < 2 ? sV[fr * GK + (ks + 1) * 4 + fk] : 0.0;
             }
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[jt], acc[jt], 0, 0, 0);
+            if constexpr (DIAG) accv = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, accv, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -114,8 +141,26 @@ __device__ __forceinline__ void gram_body(const double *__restrict__ X, int64_t 
         for (int reg = 0; reg < 4; ++reg) {
             const int gi = I * GT + wave * 16 + fk + 4 * reg;
             const int gj = J * GT + jt * 16 + fr;
-            out[(size_t)gi * ldg + gj] = acc[jt][reg];
+            if (gi < M && gj < M) out[(size_t)gi * ldg + gj] = acc[jt][reg];
         }
+    if constexpr (DIAG) {
+        if (fr < 2) {                                  // columns M (ones) and M + 1 (y) of the rows of this tile
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gi = I * GT + wave * 16 + fk + 4 * reg;
+                if (gi < M) out[(size_t)gi * ldg + M + fr] = accv[reg];
+            }
+        }
+        if (I == 0 && wave == 0) {                     // 2 x 2 corner: fixed-order butterfly over the 32 staging lanes
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {
+                c11 += __shfl_xor(c11, off); c1y += __shfl_xor(c1y, off); cyy += __shfl_xor(cyy, off);
+            }
+            if (lane == 0) {
+                out[(size_t)M * ldg + M] = c11; out[(size_t)M * ldg + M + 1] = c1y; out[(size_t)(M + 1) * ldg + M + 1] = cyy;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256, 4) void gram_kernel(const double *__restrict__ X, int64_t N, int M, int64_t ldX,
@@ -124,27 +169,35 @@ __global__ __launch_bounds__(256, 4) void gram_kernel(const double *__restrict__
 {
     __shared__ double sA[GT * GLD];
     __shared__ double sB[GT * GLD];
-    const int nt = ldg / GT;
+    __shared__ double sV[2 * GK];
+    const int nt = (M + GT - 1) / GT;                  // feature tiles only
     const int xg = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int pair = q % np, sl = q / np;
     int I = 0, rem = pair;
     while (rem >= nt - I) { rem -= nt - I; ++I; }
     const int J = I + rem;
-    // a tile is an "edge" tile when it holds a virtual column (ones at M, y at M + 1) or padding, i.e. any column >= M: that
-    // is the last tile, and ALSO the one before it when M % 64 == 63 (ones is then its last column).  I <= J.
-    const int first_edge = M / GT;
-    const bool ea = I >= first_edge, eb = J >= first_edge;
-    if (!eb) gram_body<false, false>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
-    else if (!ea) gram_body<false, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
-    else gram_body<true, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB);
+    // the last feature tile is an "edge" tile when M is not a multiple of 64 (zero padding beyond column M - 1).  I <= J.
+    const bool ragged = (M % GT) != 0;
+    const bool ea = ragged && I == nt - 1, eb = ragged && J == nt - 1;
+    if (I == J) {
+        if (ea) gram_body<true, true, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB, sV);
+        else gram_body<false, false, true>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB, sV);
+    } else {
+        if (eb) gram_body<false, true, false>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB, sV);
+        else gram_body<false, false, false>(X, N, M, ldX, y, slab, ldg, chunk_rows, S, I, J, xg, sl, sA, sB, sV);
+    }
 }
 
-__global__ void gram_reduce_kernel(const double *__restrict__ slab, int chunks, int ldg, double *__restrict__ G)
+// G[i][j] = sum over the slabs of the computed entry: features use the upper tile pair, an entry with a virtual index (ones = M,
+// y = M + 1) lives at [min(i, j)][max(i, j)].  Fixed summation order: bitwise reproducible, no float atomics.
+__global__ void gram_reduce_kernel(const double *__restrict__ slab, int chunks, int ldg, int M, double *__restrict__ G)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ldg * ldg) return;
     const int i = idx / ldg, j = idx % ldg;
-    const bool upper = (i / GT) <= (j / GT);
+    if (i > M + 1 || j > M + 1) { G[idx] = 0.0; return; }
+    const bool virt = i >= M || j >= M;
+    const bool upper = virt ? (i <= j) : ((i / GT) <= (j / GT));
     const size_t off = upper ? (size_t)i * ldg + j : (size_t)j * ldg + i;
     double s = 0.0;
     for (int c = 0; c < chunks; ++c) s += slab[(size_t)c * ldg * ldg + off];
@@ -155,7 +208,7 @@ static void gram_plan(int64_t N, int64_t M, int S_env, int cr_env, int *ldg_out,
 {
     const int n_aug = (int)M + 2;
     const int ldg = ((n_aug + GT - 1) / GT) * GT;
-    const int nt = ldg / GT, np = nt * (nt + 1) / 2;
+    const int nt = ((int)M + GT - 1) / GT, np = nt * (nt + 1) / 2;        // tile pairs over the features; ones / y ride on the diagonal
     // chunk of all columns ~ 1 MiB so that the S concurrent chunks of an XCD group stay L2 resident
     int64_t cr = ((int64_t)1 << 20) / ((int64_t)n_aug * 8);
     cr = (cr / GK) * GK;
@@ -188,7 +241,7 @@ hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int tot = ldg * ldg;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, slab, chunks, ldg, G);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, slab, chunks, ldg, (int)M, G);
     return hipGetLastError();
 }
 
