@@ -97,17 +97,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane:
 // address is a link-time constant that folds into the ds_* immediates — with a dynamic base the compiler kept ~20 slot
 // addresses in SGPRs and spilled them to VGPR lanes inside the panel steps.  ~100 KB of the CU's 160 KB.
 static constexpr int CWMAX = colw(MAXT);
-__shared__ double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
-__shared__ double Z[MB * CWMAX];                      // [MB][CW] pivot column s as of its own step
-__shared__ double U[2 * (MB + 64)];                   // [2][MB+64] pivot-row entries of the current column (+ per-lane dummies)
-__shared__ double Dinv[MB + 64];                      // 1/d_s
-__shared__ unsigned long long s_inf[16];              // [2][8] violator mask of the scan
-__shared__ unsigned long long s_bas[16];              // [2][8] basis mask of the scan
-__shared__ unsigned s_sum[16];                        // [2][8] per-wave summary of s_inf: count | tile bits << 8
-__shared__ int s_veto[2];                             // first vetoed step of a block (by block parity)
-// per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
-__shared__ double s_best[2];                          // running minimum: obj^2, pattern (as bits)
-__shared__ unsigned long long s_vmask[16 * MAXT];     // group mask of variable v
+// One struct, so that the order is ours: everything the update and the panel steps address with per-thread offsets (Z, U, Dinv,
+// the masks) sits in the first 64 KB, where base + element offset fits the 16-bit immediate of the ds_* instructions; with Z
+// behind the two panel buffers every operand read of the update loop needed its own v_add for the address.
+struct LdsImage {
+    double Z[MB * CWMAX];                      // [MB][CW] pivot column s as of its own step
+    double U[2 * (MB + 64)];                   // [2][MB+64] pivot-row entries of the current column (+ per-lane dummies)
+    double Dinv[MB + 64];                      // 1/d_s
+    unsigned long long s_inf[16];              // [2][8] violator mask of the scan
+    unsigned long long s_bas[16];              // [2][8] basis mask of the scan
+    unsigned s_sum[16];                        // [2][8] per-wave summary of s_inf: count | tile bits << 8
+    int s_veto[2];                             // first vetoed step of a block (by block parity)
+    // per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
+    double s_best[2];                          // running minimum: obj^2, pattern (as bits)
+    unsigned long long s_vmask[16 * MAXT];     // group mask of variable v
+    double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
+};
+__shared__ LdsImage lds_image;
 
 template <int T, int H>
 struct Half {
@@ -237,6 +243,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
 
+    // link-time constant addresses into the LDS image
+    double *const Pbase = lds_image.Pbase, *const Z = lds_image.Z, *const U = lds_image.U, *const Dinv = lds_image.Dinv;
+    unsigned long long *const s_inf = lds_image.s_inf, *const s_bas = lds_image.s_bas, *const s_vmask = lds_image.s_vmask;
+    unsigned *const s_sum = lds_image.s_sum;
+    int *const s_veto = lds_image.s_veto;
+    double *const s_best = lds_image.s_best;
     for (int i = tid; i < 2 * MB * CW; i += THREADS) Pbase[i] = 0.0;                   // padding rows are never gathered
     for (int i = tid; i < MB * CW; i += THREADS) Z[i] = 0.0;
     if (tid < 2 * (MB + 64)) U[tid] = 0.0;
