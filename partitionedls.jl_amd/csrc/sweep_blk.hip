@@ -207,10 +207,15 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
             Dinv[s] = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
         }
         __syncthreads();
-        const double inv = Dinv[s];
+        double inv = Dinv[s];
         double u[M];
 #pragma unroll
         for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
+        // all reads of the step are issued together, right after the barrier: left alone, the compiler sinks the u[j] loads into the
+        // "pivot accepted" branch, i.e. behind a second LDS round trip (wait for 1/d, branch, then load and wait again)
+        asm volatile("" : "+v"(inv));
+#pragma unroll
+        for (int j = 0; j < M; ++j) asm volatile("" : "+v"(u[j]));
         // leave-one-out veto: T_js^2 >= d / piv_eps  (inv = 1/d; negative for a leaving pivot, 0 for a rejected one)
         if ((pv[s] * pv[s]) * (inv * piv_eps) >= 1.0) veto = veto < s ? veto : s;
         // inv is the same in every lane: a scalar branch skips a rejected pivot (1/d = 0: exponent field 0)
