@@ -480,6 +480,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     // keep every CU busy on small problems: at least ~2 chains per CU when there are enough patterns
     while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
     const int64_t nchains = (total + chain_len - 1) / chain_len;
+    if (nchains >= (1LL << 31) || chain_len >= (1LL << 31)) { set_error("partls_opt_sweep: more than 2^31 chains in one call; split the Gray-index range"); return PARTLS_ERR_UNSUPPORTED; }
     int grid = (int)std::min<int64_t>(nchains, c->knobs.grid > 0 ? c->knobs.grid : (c->use_reg ? 4096 : 1024));
     if (grid < 1) grid = 1;
 

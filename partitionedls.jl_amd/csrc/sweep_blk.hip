@@ -276,13 +276,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     unsigned npiv = 0, nunconv = 0, nveto = 0;            // per workgroup: far below 2^32
     unsigned bc = 0, sc = 0;                              // block / scan counters (double-buffer parity)
 
-    const int64_t total = p.g_end - p.g_begin;
-    const int64_t nchains = (total + p.chain_len - 1) / p.chain_len;
+    // 32-bit loop state (the host guarantees nchains < 2^31 and chain_len < 2^31): every 64-bit scalar held across the pattern loop is
+    // an SGPR pair the allocator spills to a VGPR lane and reloads
+    const int clen = (int)p.chain_len;
+    const int nchains = (int)((p.g_end - p.g_begin + clen - 1) / clen);
 
     STAMP_DECL
-    for (int64_t chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
-        const int64_t g0 = p.g_begin + chain * p.chain_len;
-        const int64_t g1 = (g0 + p.chain_len < p.g_end) ? g0 + p.chain_len : p.g_end;
+    for (int chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+        const int64_t g0 = p.g_begin + (int64_t)chain * clen;
+        const int glen = (int)((g0 + clen < p.g_end) ? clen : p.g_end - g0);
         STAMP(5);
 #pragma unroll
         for (int s = 0; s < L::CNT; ++s) S[s] = p.T0[(size_t)(s + L::OFF) * 256 + t8];
@@ -291,8 +293,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
         basic = false;
         STAMP(6);
 
-        for (int64_t g = g0; g < g1; ++g) {
-            uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+        for (int gi = 0; gi < glen; ++gi) {
+            const uint64_t g = (uint64_t)g0 + (unsigned)gi;
+            uint64_t pat = g ^ (g >> 1);
             const uint64_t vmask = s_vmask[tid < 16 * T ? tid : 0] & (has_var ? ~0ULL : 0ULL);
             bool isfree = false;
             int f;
@@ -317,7 +320,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 ++sc;
                 bool bad = false;
                 if (has_var) {
-                    const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
+                    const double fq = q * (double)(f > 1 ? 1 : (f < -1 ? -1 : f));     // sign(f) * q  (|f| = 2: feature of two groups)
                     if (NODE && isfree) bad = !basic && !blocked && (fabs(q) > p.tol);     // free: stationarity only
                     else if (basic) bad = (f == 0) || (fq < -p.tol);
                     else bad = (fq > p.tol) && !blocked;
