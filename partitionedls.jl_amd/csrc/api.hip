@@ -475,7 +475,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     }
     const int n = c->n, ld = n + 1;
     const int64_t total = g_end - g_begin;
-    int64_t chain_len = c->knobs.chain_len > 0 ? c->knobs.chain_len : (c->use_reg ? 512 : 64);
+    int64_t chain_len = c->knobs.chain_len > 0 ? c->knobs.chain_len : (c->use_reg ? 1024 : 64);   // a chain start costs ~8 patterns' pivots
     if (chain_len < 1) chain_len = 1;
     // keep every CU busy on small problems: at least ~2 chains per CU when there are enough patterns
     while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
