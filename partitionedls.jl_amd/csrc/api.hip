@@ -134,7 +134,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
         PARTLS_HIP_CHECK(launch_layout_reg(c->Tfull.as<double>(), c->n, c->T, c->T0reg.as<double>(), c->stream));
     }
     t_end(c, PARTLS_T_PREP);
-    c->hG.resize((size_t)c->ldg * c->ldg);
+    PARTLS_HIP_CHECK(c->hG.resize((size_t)c->ldg * c->ldg));
     c->hScale.resize((size_t)c->n);
     int bad = 0;
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->hG.data(), c->G.p, c->hG.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -172,8 +172,9 @@ void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes
 }
 
 partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_t cnt, std::vector<double> &sols,
-                          std::vector<double> &obj2, unsigned long long *unconv, bool resume)
+                          std::vector<double> &obj2, unsigned long long *unconv, bool resume, bool want_tab)
 {
+    c->tab_valid = false;
     const int n = c->n, ld = n + 1;
     sols.assign(cnt * (size_t)n, 0.0);
     obj2.assign(cnt, 0.0);
@@ -212,6 +213,22 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     p.n_vetoes = c->counters.as<unsigned long long>() + 2;
     p.node_code = c->nodeCode.as<int8_t>();
     p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
+    // the caller will refine this one solution: have the register kernel leave its final tableau (refine_solution's solver)
+    const bool dump = want_tab && cnt == 1 && c->use_reg;
+    const size_t tabd = dump ? sweep_reg_t0_doubles(c->T) : 0;
+    if (dump) {
+        PARTLS_HIP_CHECK(c->nodeTab.ensure(tabd * sizeof(double)));
+        PARTLS_HIP_CHECK(c->nodeBasic.ensure((size_t)16 * c->T));
+        if (c->hTabDoubles < tabd) {                                   // pinned: the 0.3 MB copy then costs ~20 us instead of ~150
+            if (c->hTab) (void)hipHostFree(c->hTab);
+            if (c->hBasic) (void)hipHostFree(c->hBasic);
+            c->hTab = nullptr; c->hBasic = nullptr; c->hTabDoubles = 0;
+            PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hTab, tabd * sizeof(double), hipHostMallocDefault));
+            PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hBasic, (size_t)16 * 17 /* 16 x MAXT of sweep_blk.hip */, hipHostMallocDefault));
+            c->hTabDoubles = tabd;
+        }
+        p.node_tab = c->nodeTab.as<double>(); p.node_basic = c->nodeBasic.as<int8_t>();
+    }
     if (coop) {
         // one large problem: many workgroups cooperate on a single global-memory tableau (sweep_coop.hip)
         p.T0 = c->Tfull.as<double>();
@@ -229,8 +246,13 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->nodeSol.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(obj2.data(), c->nodeObj.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    if (dump) {
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->nodeTab.p, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->hBasic, c->nodeBasic.p, (size_t)16 * c->T, hipMemcpyDeviceToHost, c->stream));
+    }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (unconv) *unconv = counters[0];
+    c->tab_valid = dump && counters[0] == 0;
     return PARTLS_OK;
 }
 
@@ -280,6 +302,31 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         if (w[(size_t)m] != 0.0 || (m == (int)M && free_intercept)) sup.push_back(m);
     const int p = (int)sup.size();
     if (p == 0) return PARTLS_OK;
+    // Solver of the correction equations.  With the final tableau of the node solve at hand (register kernel), its basic x basic
+    // block is -(D B_BB D)^-1 (D = unit-diagonal scaling, B = regularised Gram, with the free intercept already eliminated by its
+    // Schur complement): delta_B = -D T_BB D rhs is one p x p matrix-vector product per step instead of a p^3/6 factorisation.
+    // Valid when the basis IS the support (a basic variable that came out exactly 0 would not be in `sup`): otherwise Cholesky.
+    std::vector<int> tabsup;                             // tableau indices of the support, when the tableau path applies
+    bool use_tab = c->tab_valid && free_intercept == !c->faithful;
+    c->tab_valid = false;                                // one use: the next node solve overwrites the buffers
+    if (use_tab) {
+        std::vector<int> inv_perm((size_t)M + 1, -1);
+        for (int i = 0; i < c->n; ++i) inv_perm[(size_t)c->perm[(size_t)i]] = i;
+        int nb = 0;
+        for (int i = 0; i < c->n; ++i) nb += c->hBasic[i] ? 1 : 0;
+        for (int m : sup) {
+            if (m == (int)M && !c->faithful) continue;   // free intercept: eliminated from the tableau, recovered below
+            const int i = inv_perm[(size_t)m];
+            if (i < 0 || !c->hBasic[i]) { use_tab = false; break; }
+            tabsup.push_back(i);
+        }
+        if ((int)tabsup.size() != nb) use_tab = false;
+    }
+    auto tab_entry = [&](int i, int j) -> double {       // T(i, j) of the dumped tableau (tile-cyclic layout of T0, upper tiles stored)
+        int ti = i >> 4, tj = j >> 4, a = i & 15, b = j & 15;
+        if (ti > tj) { std::swap(ti, tj); std::swap(a, b); }
+        return c->hTab[((size_t)(tj * (tj + 1) / 2 + ti)) * 256 + a + 16 * b];
+    };
     PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
     PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
     PARTLS_HIP_CHECK(c->gD.ensure((size_t)(M + 1) * sizeof(double)));
@@ -314,7 +361,7 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
                                          c->yhatD.as<double>(), c->stream));
         PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, c->yhatD.as<double>(), c->gD.as<double>(), c->stream));
         bool spd = true;
-        if (it == 0) spd = factorise();                      // overlaps with the kernels just queued (the copy below waits for them)
+        if (it == 0 && !use_tab) spd = factorise();          // overlaps with the kernels just queued (the copy below waits for them)
         PARTLS_HIP_CHECK(hipMemcpyAsync(g.data(), c->gD.p, (size_t)(M + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
@@ -324,6 +371,38 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
                 for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) gs += w[(size_t)m];
                 for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) g[(size_t)m] -= c->eta * gs;
             }
+        }
+        if (use_tab) {
+            const int nb = (int)tabsup.size();
+            const bool elim = !c->faithful;                  // free intercept: rhs and solution go through its Schur complement
+            const double gII = elim ? h_reg(c, (int)M, (int)M) : 1.0, gI = g[(size_t)M];
+            std::vector<double> rhs((size_t)nb), ds((size_t)nb);
+            for (int a = 0; a < nb; ++a) {
+                const int i = tabsup[(size_t)a], m = c->perm[(size_t)i];
+                double r = g[(size_t)m];
+                if (elim) r -= h_reg(c, m, (int)M) * gI / gII;
+                rhs[(size_t)a] = r * c->hScale[(size_t)i];
+            }
+            for (int a = 0; a < nb; ++a) {
+                double s0 = 0.0, s1 = 0.0;
+                int b = 0;
+                for (; b + 1 < nb; b += 2) {
+                    s0 += tab_entry(tabsup[(size_t)a], tabsup[(size_t)b]) * rhs[(size_t)b];
+                    s1 += tab_entry(tabsup[(size_t)a], tabsup[(size_t)b + 1]) * rhs[(size_t)b + 1];
+                }
+                if (b < nb) s0 += tab_entry(tabsup[(size_t)a], tabsup[(size_t)b]) * rhs[(size_t)b];
+                ds[(size_t)a] = -(s0 + s1);
+            }
+            double dn = 0.0, wn = 0.0, dI = gI;
+            for (int a = 0; a < nb; ++a) {
+                const int i = tabsup[(size_t)a], m = c->perm[(size_t)i];
+                const double dl = ds[(size_t)a] * c->hScale[(size_t)i];
+                if (elim) dI -= h_reg(c, (int)M, m) * dl;
+                w[(size_t)m] += dl; dn += dl * dl; wn += w[(size_t)m] * w[(size_t)m];
+            }
+            if (elim) { dI /= gII; w[(size_t)M] += dI; dn += dI * dI; wn += w[(size_t)M] * w[(size_t)M]; }
+            if (dn <= 1e-18 * wn) break;
+            continue;
         }
         for (int i = 0; i < p; ++i) {                        // L z = g_P
             double s = g[(size_t)sup[(size_t)i]];
@@ -439,8 +518,11 @@ void partls_destroy(partls_ctx *c)
         DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
                           &c->flag, &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
-                          &c->predX, &c->predY};
+                          &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic};
         for (DevBuf *b : bufs) b->release();
+        c->hG.release();
+        if (c->hTab) (void)hipHostFree(c->hTab);
+        if (c->hBasic) (void)hipHostFree(c->hBasic);
         for (int w = 0; w < PARTLS_T_COUNT; ++w) {
             if (c->ev0[w]) (void)hipEventDestroy(c->ev0[w]);
             if (c->ev1[w]) (void)hipEventDestroy(c->ev1[w]);
@@ -555,7 +637,7 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     const auto f0 = std::chrono::steady_clock::now();
     std::vector<int8_t> codes;
     opt_codes(c, (uint64_t)pattern & kmask, codes);
-    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv);
+    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
     if (st != PARTLS_OK) return st;
     const auto f1 = std::chrono::steady_clock::now();
     unscale_solution(c, sols.data(), w);
@@ -596,7 +678,7 @@ partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alp
     unsigned long long unconv = 0;
     std::vector<int8_t> codes;
     opt_codes(c, (uint64_t)pattern, codes);
-    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv);
+    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
     if (st != PARTLS_OK) return st;
     unscale_solution(c, sols.data(), w);
     st = refine_solution(c, w, false);

@@ -51,6 +51,11 @@ struct SweepParams {
     double *node_sol;
     double *node_obj2;
     int node_ld;
+    // optional (register kernel, node mode): the final tableau of node c in the tile-cyclic layout of T0 (sweep_reg_t0_doubles per
+    // node) and its basis flags [16 T per node] — the basic x basic block is -(B_BB)^-1 on the unit-diagonal scale, which the
+    // winner's iterative refinement uses as its solver (api.hip: refine_solution)
+    double *node_tab;
+    int8_t *node_basic;
     // cooperative single-node kernel only: continue from the tableau / basis left in `scratch` by the previous launch
     // (warm start of consecutive Alt alpha-steps) instead of reloading T0
     int resume;

@@ -20,6 +20,28 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// page-locked host array of doubles (device -> host copies at full PCIe rate instead of through a staging buffer)
+struct PinnedDoubles {
+    double *p = nullptr;
+    size_t cap = 0, n = 0;
+    hipError_t resize(size_t count)
+    {
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            hipError_t e = hipHostMalloc((void **)&p, (count ? count : 1) * sizeof(double), hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            cap = count;
+        }
+        n = count;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = n = 0; }
+    double *data() const { return p; }
+    size_t size() const { return n; }
+    double &operator[](size_t i) const { return p[i]; }
+};
+
 }  // namespace partls
 
 // Tuning / diagnostic knobs, read from the environment ONCE at partls_create (never on the per-call path).
@@ -55,8 +77,9 @@ struct partls_ctx {
     // gram
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
-        wdev, partial, flag, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr;
-    std::vector<double> hG, hScale;
+        wdev, partial, flag, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic;
+    partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
+    std::vector<double> hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
     int n = 0, kbits = 0, T = 0;
     std::vector<int> perm;
@@ -65,6 +88,11 @@ struct partls_ctx {
     double tol = 0.0;
     unsigned long long last_pivots = 0, last_vetoes = 0;
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
+    // final tableau of the last single-node solve on the register kernel (pinned host copies; see solve_nodes `want_tab`)
+    double *hTab = nullptr;
+    int8_t *hBasic = nullptr;
+    size_t hTabDoubles = 0;
+    bool tab_valid = false;
 };
 
 namespace partls {
@@ -81,7 +109,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
 // tableau variable v in node i: +1 (w >= 0), -1 (w <= 0), 0 (w = 0), 2 (free) — see SweepParams::node_code.  sols: cnt x n
 // scaled solutions in tableau order (0 for nonbasic); obj2: objective^2 from the tableau corner.
 partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_t cnt, std::vector<double> &sols,
-                          std::vector<double> &obj2, unsigned long long *unconv, bool resume = false);
+                          std::vector<double> &obj2, unsigned long long *unconv, bool resume = false, bool want_tab = false);
 // node codes of one Opt sign pattern (Opt.jl:28-29): sign of the multiplier sum_k P[m,k] s_k of every tableau variable
 void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes);
 
@@ -90,7 +118,8 @@ void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double
 // ||Xo w - yo||_2 from the data (+ the eta rows): Opt.jl:90
 partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt);
 // Iterative refinement of a solution w (over [features, intercept]) on its own support, in data space: residual and
-// X'r on the device, the small SPD solve on the host Gram copy.  Brings a Gram-based solution (error ~ cond^2 eps) to the
+// X'r on the device; the small SPD solve uses the inverse the pivoting left in the final tableau of the node solve (want_tab;
+// register kernel) or, without one, a Cholesky factorisation of the host Gram copy.  Brings a Gram-based solution (error ~ cond^2 eps) to the
 // accuracy of a QR-based one (the reference's NNLS) as long as cond^2 eps < 1.  `free_intercept`: the intercept is part
 // of the support even when w[M] == 0.
 partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps = 2);

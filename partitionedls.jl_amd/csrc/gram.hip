@@ -396,6 +396,8 @@ static void gram_plan(int64_t N, int64_t M, int S_env, int cr_env, int *ldg_out,
             if (S < 1) S = 1;
             if (k == 1 || panels / ((int64_t)8 * S) >= 64) break;
         }
+        // small problems: a workgroup needs >= 8 panels to be worth its 128 KB tile write and its share of the reduction
+        if (panels / ((int64_t)8 * S) < 8) { S = (int)(panels / 64); if (S < 1) S = 1; }
     }
     // no more slices than chunks: shrink the chunks before giving up slices
     if (cr_env <= 0 && (N + cr - 1) / cr < (int64_t)8 * S) {

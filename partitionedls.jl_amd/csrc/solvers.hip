@@ -247,7 +247,7 @@ partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, doubl
     }
     std::vector<double> sols, obj2, w;
     unsigned long long unconv = 0;
-    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv);
+    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
     if (st != PARTLS_OK) return st;
     unscale_solution(c, sols.data(), w);
     st = refine_solution(c, w, false);

@@ -496,6 +496,12 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
         if constexpr (NODE) {
             if (has_var) p.node_sol[(size_t)chain * p.node_ld + tid] = basic ? q : 0.0;
             if (tid == 0) p.node_obj2[chain] = corner;
+            if (p.node_tab && (H == 0 || T > 1)) {                // final tableau + basis, same layout as T0 (half 1 of T = 1 owns nothing)
+                double *tab = p.node_tab + (size_t)chain * (nslots(T) * 256 + 16 * T + 8);
+#pragma unroll
+                for (int s = 0; s < L::CNT; ++s) tab[(size_t)(s + L::OFF) * 256 + t8] = S[s];
+                if (tid < 16 * T) p.node_basic[(size_t)chain * 16 * T + tid] = basic ? 1 : 0;
+            }
         }
     }
     STAMP_FLUSH;
