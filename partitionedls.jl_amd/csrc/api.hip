@@ -518,7 +518,7 @@ void partls_destroy(partls_ctx *c)
         DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
                           &c->flag, &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
-                          &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic};
+                          &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic, &c->altA, &c->altGA, &c->altHg};
         for (DevBuf *b : bufs) b->release();
         c->hG.release();
         if (c->hTab) (void)hipHostFree(c->hTab);

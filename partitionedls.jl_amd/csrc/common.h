@@ -83,6 +83,9 @@ hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64
                        const int *perm, double *scale, double *Tfull, int n, hipStream_t s);
 
 // residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
+// beta-step system of fit(Alt): Hg[k * (Kp + 1) + k2] = H[k][k2] (k2 < Kp), g[k] (k2 = Kp); GA is (M + 1) x Kp scratch
+hipError_t launch_alt_beta_system(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, const double *a, int Kp,
+                                  double *GA, double *Hg, hipStream_t s);
 hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *w, double t,
                            double *partial, int nblocks, double *yhat, hipStream_t s);
 // g[0..M] = Xo' (y - yhat): the gradient pass of the data-space refinement

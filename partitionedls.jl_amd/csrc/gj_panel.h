@@ -35,26 +35,26 @@ __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double
     int accepted = 0;
     for (int s = 0; s < m; ++s) {
         const int k = ks[s];
-        // entries of the pivot COLUMN s at the pivot rows (not of column j at row k: equal only in exact arithmetic — with the
-        // factor taken from column s the panel receives exactly the symmetric rank-1 term z_s z_s'/d_s of the fused update;
-        // mixing the two loses the solution on ill-conditioned data, see sweep_blk.hip)
+        // Two barriers per step.  Before the first: the entries of the pivot COLUMN s at the pivot rows are published (not of column j
+        // at row k: equal only in exact arithmetic — with the factor taken from column s the panel receives exactly the symmetric
+        // rank-1 term z_s z_s'/d_s of the fused update; mixing the two loses the solution on ill-conditioned data, see
+        // sweep_blk.hip), and every wave leaves its part of max_i T_ik^2 over the variable rows (nonbasic rows satisfy
+        // T_ik^2 <= d_k, so only a basic row can trip the leave-one-out test) — computed unconditionally: cheaper than a barrier.
         if (tid < m) uj[tid] = Pn[(size_t)s * ld + ks[tid]];
+        double c2 = 0.0;
+        for (int i = tid; i < ld - 1; i += NT)
+            if (i != k) { const double z = Pn[(size_t)s * ld + i]; c2 = fmax(c2, z * z); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c2 = fmax(c2, __shfl_xor(c2, off));
+        if ((tid & 63) == 0) red[tid >> 6] = c2;
         __syncthreads();
         const double d = uj[s];
         const bool bas = s_basic[k] != 0;
         bool ok = bas || (d > piv_eps);
         if (ok && !bas) {                                                // uniform
-            double c2 = 0.0;
-            for (int i = tid; i < ld - 1; i += NT)                       // every variable row (nonbasic rows satisfy T_ik^2 <= d_k)
-                if (i != k) { const double z = Pn[(size_t)s * ld + i]; c2 = fmax(c2, z * z); }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c2 = fmax(c2, __shfl_xor(c2, off));
-            if ((tid & 63) == 0) red[tid >> 6] = c2;
-            __syncthreads();
             double cmax2 = 0.0;
             for (int w = 0; w < NT / 64; ++w) cmax2 = fmax(cmax2, red[w]);
             ok = !(cmax2 * piv_eps >= d);
-            __syncthreads();
         }
         const double inv = ok ? 1.0 / d : 0.0, ainv = fabs(inv);
         if (ok) {
@@ -72,8 +72,8 @@ __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double
             }
         }
         if (tid == 0) dinv[s] = inv;
-        __syncthreads();
-        if (ok && tid == 0) s_basic[k] ^= 1;                             // everybody has read the old flag; next read is behind a barrier
+        __syncthreads();                                                 // panel, uj, red and the old basis flag are done with
+        if (ok && tid == 0) s_basic[k] ^= 1;                             // the next read of THIS flag is behind a later barrier
     }
     __syncthreads();
     return accepted;

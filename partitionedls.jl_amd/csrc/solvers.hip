@@ -23,25 +23,6 @@ using namespace partls;
 
 namespace {
 
-// w'Gw - 2 w'c + yy on the regularised host Gram copy (w over [features, intercept])
-double gram_objective2(const partls_ctx *c, const std::vector<double> &w)
-{
-    const int Mp = (int)c->M + 1, Y = (int)c->M + 1;
-    double s = h_reg(c, Y, Y);
-    for (int i = 0; i < Mp; ++i) {
-        if (w[(size_t)i] == 0.0) continue;
-        double gi = 0.0;
-        if (c->eta == 0.0) {
-            const double *Grow = &c->hG[(size_t)i * c->ldg];
-            for (int j = 0; j < Mp; ++j) gi += Grow[j] * w[(size_t)j];
-        } else {
-            for (int j = 0; j < Mp; ++j) gi += h_reg(c, i, j) * w[(size_t)j];
-        }
-        s += w[(size_t)i] * (gi - 2.0 * h_reg(c, i, Y));
-    }
-    return s;
-}
-
 // dense solve H x = g (n x n, row-major), Gaussian elimination with partial pivoting; false if singular
 bool solve_dense(std::vector<double> &H, std::vector<double> &g, int n)
 {
@@ -131,36 +112,32 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         for (int m = 0; m < Mp; ++m) for (int k : groups_of[(size_t)m]) poa[(size_t)m] += suma[(size_t)k];        // Po * sumα'
         for (int m = 0; m < Mp; ++m) a[(size_t)m] /= poa[(size_t)m];                 // a feature in no group: 0/0 = NaN, as in the reference
         for (int k = 0; k < Kp; ++k) b[(size_t)k] *= suma[(size_t)k];
-        // ---- β-step: (A' G A) β = A' c,  A = Po∘α  (Alt.jl:109-110 in Gram form) ---------------------------------------------
-        std::vector<double> H((size_t)Kp * Kp, 0.0), g((size_t)Kp, 0.0), ga((size_t)Kp, 0.0);
-        for (int m = 0; m < Mp; ++m) {
-            if (groups_of[(size_t)m].empty() || a[(size_t)m] == 0.0) continue;
-            const double am = a[(size_t)m];
-            for (int k : groups_of[(size_t)m]) g[(size_t)k] += am * h_reg(c, m, Y);
-            // row m of G A: (G A)[m][k2] = sum_{m2} G[m][m2] a_{m2} [m2 in k2]
-            std::fill(ga.begin(), ga.end(), 0.0);
-            if (c->eta == 0.0) {                                   // plain Gram row: no per-entry call (M^2 entries per iteration)
-                const double *Grow = &c->hG[(size_t)m * c->ldg];
-                for (int m2 = 0; m2 < Mp; ++m2) {
-                    const double v = Grow[m2] * a[(size_t)m2];
-                    for (int k2 : groups_of[(size_t)m2]) ga[(size_t)k2] += v;
-                }
-            } else {
-                for (int m2 = 0; m2 < Mp; ++m2) {
-                    if (a[(size_t)m2] == 0.0) continue;
-                    const double v = h_reg(c, m, m2) * a[(size_t)m2];
-                    for (int k2 : groups_of[(size_t)m2]) ga[(size_t)k2] += v;
-                }
-            }
-            for (int k : groups_of[(size_t)m]) for (int k2 = 0; k2 < Kp; ++k2) H[(size_t)k * Kp + k2] += am * ga[(size_t)k2];
+        // ---- β-step: (A' G A) β = A' c,  A = Po∘α  (Alt.jl:109-110 in Gram form); the system is assembled on the device ---------
+        std::vector<double> Hg((size_t)Kp * (Kp + 1)), H((size_t)Kp * Kp), g((size_t)Kp);
+        PARTLS_HIP_CHECK(c->altA.ensure((size_t)Mp * sizeof(double)));
+        PARTLS_HIP_CHECK(c->altGA.ensure((size_t)Mp * Kp * sizeof(double)));
+        PARTLS_HIP_CHECK(c->altHg.ensure(Hg.size() * sizeof(double)));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->altA.p, a.data(), (size_t)Mp * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PARTLS_HIP_CHECK(launch_alt_beta_system(c->G.as<double>(), c->ldg, (int)M, c->eta, c->maskAugD.as<uint64_t>(), c->altA.as<double>(), Kp,
+                                                c->altGA.as<double>(), c->altHg.as<double>(), c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(Hg.data(), c->altHg.p, Hg.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (int k = 0; k < Kp; ++k) {
+            for (int k2 = 0; k2 < Kp; ++k2) H[(size_t)k * Kp + k2] = Hg[(size_t)k * (Kp + 1) + k2];
+            g[(size_t)k] = Hg[(size_t)k * (Kp + 1) + Kp];
         }
         // groups without members (possible only for user groups with no feature) get a unit diagonal so H stays regular
         for (int k = 0; k < Kp; ++k) if (H[(size_t)k * Kp + k] == 0.0) H[(size_t)k * Kp + k] = 1.0;
+        const std::vector<double> H0 = H, g0 = g;            // solve_dense eliminates in place
         if (!solve_dense(H, g, Kp)) { set_error("partls_fit_alt: singular beta-step system"); return PARTLS_ERR_NOT_CONVERGED; }
         b = g;
-        // ---- loss (Alt.jl:112-113) -----------------------------------------------------------------------------------------
-        w_from();
-        const double o2 = gram_objective2(c, w);
+        // ---- loss (Alt.jl:112-113): ||Xo (Po∘α) β - y||^2 = β' H β - 2 g' β + y'y  (w = A β; K'^2 work instead of M^2) ----------------
+        double o2 = h_reg(c, Y, Y);
+        for (int k = 0; k < Kp; ++k) {
+            double hb = 0.0;
+            for (int k2 = 0; k2 < Kp; ++k2) hb += H0[(size_t)k * Kp + k2] * b[(size_t)k2];
+            o2 += b[(size_t)k] * (hb - 2.0 * g0[(size_t)k]);
+        }
         oldopt = optval;
         optval = std::sqrt(o2 > 0.0 ? o2 : 0.0);
         if (c->knobs.alt_trace) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms, rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
