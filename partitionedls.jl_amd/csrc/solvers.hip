@@ -189,17 +189,25 @@ partls_status partls_bnb_bound(partls_ctx *c, int64_t count, const uint64_t *pat
     unsigned long long unconv = 0;
     partls_status st = solve_nodes(c, codes, (size_t)count, sols, obj2, &unconv);
     if (st != PARTLS_OK) return st;
+    // nu_k = sum_{i<j in group k} max(0, -w_i w_j) = (sum w+)(sum |w-|)  (BnB.jl:42-57); only free groups can mix signs.
+    // One pass over the variables per node (the groups of a variable come from its mask bits), not one pass per group.
+    std::vector<double> pos((size_t)Kp), neg((size_t)Kp);
     for (int64_t i = 0; i < count; ++i) {
         lb[i] = std::sqrt(obj2[(size_t)i] > 0.0 ? obj2[(size_t)i] : 0.0);
         unscale_solution(c, sols.data() + (size_t)i * (size_t)n, w);
-        // nu_k = sum_{i<j in group k} max(0, -w_i w_j) = (sum w+)(sum |w-|)  (BnB.jl:42-57); only free groups can mix signs
+        std::fill(pos.begin(), pos.end(), 0.0);
+        std::fill(neg.begin(), neg.end(), 0.0);
+        for (int m = 0; m < Mp; ++m) {
+            const double wm = w[(size_t)m];
+            if (wm == 0.0) continue;
+            for (uint64_t bits = c->mask_aug[(size_t)m] & free_[i]; bits; bits &= bits - 1) {
+                const int k = __builtin_ctzll(bits);
+                if (wm > 0.0) pos[(size_t)k] += wm; else neg[(size_t)k] -= wm;
+            }
+        }
         int kbest = -1; double nubest = 0.0;
         for (int k = 0; k < Kp; ++k) {
-            if (!((free_[i] >> k) & 1ULL)) continue;
-            double pos = 0.0, neg = 0.0;
-            for (int m = 0; m < Mp; ++m)
-                if ((c->mask_aug[(size_t)m] >> k) & 1ULL) { if (w[(size_t)m] > 0.0) pos += w[(size_t)m]; else neg -= w[(size_t)m]; }
-            const double nu = pos * neg;
+            const double nu = pos[(size_t)k] * neg[(size_t)k];
             if (nu > nubest) { nubest = nu; kbest = k; }                   // argmax: first maximal index
         }
         branch[i] = kbest;

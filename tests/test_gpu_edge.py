@@ -127,11 +127,13 @@ def test_ill_conditioned_model_parity(partls, oracle, noise, tol):
         assert abs(m.t - ref["t"]) < tol
 
 
-@pytest.mark.parametrize("M", [63, 64, 65, 127, 191, 255])
+@pytest.mark.parametrize("M", [1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 300, 385])
 def test_gram_virtual_columns_at_tile_boundaries(partls, M):
-    """The ones / y columns of Z = [X 1 y] are virtual; when M % 64 == 63 the ones column is the LAST column of the tile before
-    the last one (found by tests/test_gpu_fuzz.py: G[M][M] came out 0).  Gram block against numpy, and a fit against the
-    oracle-independent normal equations of the unconstrained winner."""
+    """The ones / y columns of Z = [X 1 y] are virtual (they ride on the diagonal 128 x 128 tiles as extra 16 x 16 accumulators); the
+    feature tiles are 128 wide with a zero-padded edge tile, the diagonal tiles store their upper triangle at 16 x 16 granularity.
+    M around every multiple of 16 / 64 / 128 that matters (round 1: at M % 64 == 63 G[M][M] came out 0, found by the fuzz
+    campaign).  N = 3 M + 17 is never a multiple of the 16-sample panel: the last panel of the data is partial.  Gram block
+    against numpy."""
     rng = np.random.default_rng(700 + M)
     N, K = 3 * M + 17, 5
     X = rng.standard_normal((N, M))
