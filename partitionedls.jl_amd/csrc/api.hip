@@ -224,7 +224,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
             if (c->hBasic) (void)hipHostFree(c->hBasic);
             c->hTab = nullptr; c->hBasic = nullptr; c->hTabDoubles = 0;
             PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hTab, tabd * sizeof(double), hipHostMallocDefault));
-            PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hBasic, (size_t)16 * 17 /* 16 x MAXT of sweep_blk.hip */, hipHostMallocDefault));
+            PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hBasic, (size_t)16 * 32 /* >= 16 x MAXT of sweep_blk.hip */, hipHostMallocDefault));
             c->hTabDoubles = tabd;
         }
         p.node_tab = c->nodeTab.as<double>(); p.node_basic = c->nodeBasic.as<int8_t>();

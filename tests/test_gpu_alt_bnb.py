@@ -108,11 +108,11 @@ def test_overlapping_partition_accepted_for_alt_bnb(partls, oracle):
 
 
 def test_alt_and_opt_beyond_register_kernel(partls, oracle):
-    """n = 301 > 272: enumeration on the global-memory kernel, single solves (Alt alpha-steps, winner re-solve) on the
+    """n = 321 > 304: enumeration on the global-memory kernel, single solves (Alt alpha-steps, winner re-solve) on the
     cooperative multi-workgroup kernel; both against the dense oracle."""
-    X, y, P, _ = oracle.synth(20260150, 1500, 300, 4)
+    X, y, P, _ = oracle.synth(20260150, 1500, 320, 4)
     rng = np.random.default_rng(5)
-    a0 = rng.random(301); b0 = (rng.random(5) - 0.5) * 10
+    a0 = rng.random(321); b0 = (rng.random(5) - 0.5) * 10
     ref = oracle.fit_alt(X, y, P, a0, b0)
     m, _, rep = partls.fit(partls.Alt, X, y, P, alpha0=a0, beta0=b0)
     assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])

@@ -155,9 +155,10 @@ def test_fuzz_alt_same_start_vs_oracle(partls, oracle, block):
                                    atol=1e-6 * max(1.0, float(np.linalg.norm(y))), err_msg=tag)
 
 
-@pytest.mark.parametrize("D", [273, 300, 340])
+@pytest.mark.parametrize("D", [273, 300, 305, 340])
 def test_fuzz_large_n_generic_path_vs_oracle(partls, oracle, D):
-    """n > 272 variables: the global-memory tableau kernels (sweep_generic.hip chains, sweep_coop.hip single nodes)."""
+    """the top of the register kernel's range (n = 274, 301: T = 18, 19 tile columns) and, beyond n = 304, the global-memory
+    tableau kernels (sweep_generic.hip chains, sweep_coop.hip single nodes)."""
     rng = np.random.default_rng(9900 + D)
     K = 3
     N = 2 * D + 11
