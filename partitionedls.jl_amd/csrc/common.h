@@ -65,7 +65,7 @@ struct SweepParams {
 // launchers (each returns hipError_t of the launch)
 hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s);
-hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 304)
+hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 320)
 bool       sweep_reg_supported(int n);
 int        sweep_reg_tiles(int n);
 size_t     sweep_reg_t0_doubles(int T);                  // size of the tile-cyclic initial tableau

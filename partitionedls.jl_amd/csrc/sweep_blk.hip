@@ -1,4 +1,4 @@
-// sweep_blk.hip — production sign-pattern sweep, BLOCKED principal pivots on a register-resident tableau (n <= 304).
+// sweep_blk.hip — production sign-pattern sweep, BLOCKED principal pivots on a register-resident tableau (n <= 320).
 //
 // Replaces the loop body of fit(Opt), Opt.jl:87-90 (indextobeta + bmatrix + nonneg_lsq + objective), for every pattern of a
 // Gray-code chain, and serves the node solves of Alt (Alt.jl:80-90) and BnB (BnB.jl:69-92); same mathematics and the same
@@ -40,7 +40,7 @@ namespace partls {
 namespace blk {
 
 static constexpr int THREADS = 512;
-static constexpr int MAXT = 19;                 // n <= 304
+static constexpr int MAXT = 20;                 // n <= 320 (T = 21 already runs no faster than the global-memory kernel: 1500 spilled VGPRs)
 #ifndef PARTLS_UPD_UNROLL
 #define PARTLS_UPD_UNROLL 1
 #endif
@@ -235,7 +235,7 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
     return veto;
 }
 
-#define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18)
+#define PARTLS_CASES(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19)
 
 // NODE: node mode (Alt alpha-steps, BnB bounds: one subproblem per chain, free / zero groups) is a separate instantiation, so
 // that the chain-mode sweep carries neither the node pointers nor the per-thread `free` flag through its loops.

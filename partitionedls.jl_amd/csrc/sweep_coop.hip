@@ -1,6 +1,6 @@
 // sweep_coop.hip — ONE large subproblem solved by many workgroups (grid-wide barriers), BLOCKED pivots.
 //
-// Used for single "node" solves whose tableau does not fit the register-resident kernel (n > 304): the α-step of
+// Used for single "node" solves whose tableau does not fit the register-resident kernel (n > 320): the α-step of
 // fit(Alt) at BASELINE config 4 (n = 513, Alt.jl:80-90) and the winner re-solve of fit(Opt) at such sizes.  Same
 // algorithm and decisions as sweep_generic.hip; the (n+1)^2 tableau lives in global memory (2.1 MB at n = 513,
 // L2 resident) and every workgroup owns a slice of its ROWS.  All control state (basis flags, rejections, the violator

@@ -108,7 +108,7 @@ def test_overlapping_partition_accepted_for_alt_bnb(partls, oracle):
 
 
 def test_alt_and_opt_beyond_register_kernel(partls, oracle):
-    """n = 321 > 304: enumeration on the global-memory kernel, single solves (Alt alpha-steps, winner re-solve) on the
+    """n = 321 > 320: enumeration on the global-memory kernel, single solves (Alt alpha-steps, winner re-solve) on the
     cooperative multi-workgroup kernel; both against the dense oracle."""
     X, y, P, _ = oracle.synth(20260150, 1500, 320, 4)
     rng = np.random.default_rng(5)

@@ -56,7 +56,7 @@ def test_c4_full_size_alt(partls):
 
 
 def test_alt_d512_vs_oracle_same_start(partls, oracle):
-    """Alt at the C4 feature shape (D = 512, K = 16 -> n = 513 > 304: cooperative kernel for the alpha-step) on an N the dense
+    """Alt at the C4 feature shape (D = 512, K = 16 -> n = 513 > 320: cooperative kernel for the alpha-step) on an N the dense
     oracle can afford, from the same (alpha0, beta0): Alt.jl:77-117 iterates are deterministic, so objective and model agree."""
     seed, N, D, K = 20260004, 2000, 512, 16
     X, y, P, _ = oracle.synth(seed, N, D, K)

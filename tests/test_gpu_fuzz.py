@@ -157,7 +157,7 @@ def test_fuzz_alt_same_start_vs_oracle(partls, oracle, block):
 
 @pytest.mark.parametrize("D", [273, 300, 305, 340])
 def test_fuzz_large_n_generic_path_vs_oracle(partls, oracle, D):
-    """the top of the register kernel's range (n = 274, 301: T = 18, 19 tile columns) and, beyond n = 304, the global-memory
+    """the top of the register kernel's range (n = 274, 301, 306: T = 18, 19, 20 tile columns) and, beyond n = 320, the global-memory
     tableau kernels (sweep_generic.hip chains, sweep_coop.hip single nodes)."""
     rng = np.random.default_rng(9900 + D)
     K = 3

@@ -1,4 +1,4 @@
-"""Sweep timing at any D (register kernel up to n = 304, sweep_generic.hip beyond): python tools/generic_timing.py N D K"""
+"""Sweep timing at any D (register kernel up to n = 320, sweep_generic.hip beyond): python tools/generic_timing.py N D K"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch, partls_amd
