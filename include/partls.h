@@ -53,7 +53,7 @@ partls_status partls_create(int device, partls_ctx **out);
 void          partls_destroy(partls_ctx *ctx);
 
 /* ---- fit(Opt, X, y, P; η, returnAllSolutions)  — replaces Opt.jl:73-104 ----------------------------------------------
- * X: N x M (ldX >= N), y: N, P: M x K (ldP >= M).  Outputs follow cleanupResult (Opt.jl:34-44):
+ * X: N x M (N <= ldX < 2^30), y: N, P: M x K (ldP >= M).  Outputs follow cleanupResult (Opt.jl:34-44):
  *   alpha[M] (sums to 1 per group), beta[K], *t, *opt = ||Xo w - yo||_2 of the winner (un-squared, incl. the η rows),
  *   *best_index = the reference's 0-based pattern index b (bit k = sign of group k+1, bit K = intercept sign; in
  *   free-intercept mode bit K is set from the sign of the fitted intercept).

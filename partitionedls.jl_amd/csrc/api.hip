@@ -40,6 +40,7 @@ partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, i
     if (!X || !P) { set_error("X or P is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (N < 1 || M < 1 || K < 1) { set_error("need N, M, K >= 1 (got %lld, %lld, %lld)", (long long)N, (long long)M, (long long)K); return PARTLS_ERR_BAD_ARG; }
     if (ldX < N || ldP < M) { set_error("leading dimension smaller than the row count"); return PARTLS_ERR_BAD_ARG; }
+    if (ldX >= ((int64_t)1 << 30)) { set_error("ldX = %lld: this build supports leading dimensions below 2^30 rows", (long long)ldX); return PARTLS_ERR_UNSUPPORTED; }
     if (K > 39) { set_error("K = %lld groups: 2^(K+1) sign patterns is out of range (K <= 39)", (long long)K); return PARTLS_ERR_UNSUPPORTED; }
     if (M + 1 > 1023) { set_error("M = %lld features: this build supports M <= 1022", (long long)M); return PARTLS_ERR_UNSUPPORTED; }
     return PARTLS_OK;

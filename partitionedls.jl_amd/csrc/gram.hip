@@ -51,7 +51,7 @@ static constexpr int NL = GT / (NWV * CPW);    // loads per thread, panel and ma
 //   z_load  : unconditional load from a clamped address (issued one panel ahead, result untouched),
 //   z_value : zero for the padding columns of the last tile (EDGE) and for the row tail, applied at the LDS store.
 // Addresses: wave-uniform 64-bit base (tile column block, panel row: SGPRs) + ONE per-lane 32-bit element offset shared by all the
-// loads of a panel (csub * ldX + row in panel), so the 2 x NL loads in flight cost no address registers (the host refuses ldX >= 2^27).
+// loads of a panel (csub * ldX + row in panel), so the 2 x NL loads in flight cost no address registers (element offsets, not bytes: 3 * ldX + 15 must fit 32 bits; the host refuses ldX >= 2^30).
 template <bool EDGE>
 __device__ __forceinline__ double z_load(const double *__restrict__ Xrow, int64_t ldX, int M, int colu, int csub, unsigned lane_off, unsigned rowoff)
 {
@@ -423,7 +423,7 @@ hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const
 {
     int ldg2, S, cr, np, nt;
     gram_plan(N, M, gram_S, gram_cr, &ldg2, &S, &cr, &np, &nt);
-    if (ldX >= ((int64_t)1 << 27)) return hipErrorInvalidValue;          // 32-bit per-lane element offsets (see z_load)
+    if (ldX >= ((int64_t)1 << 30)) return hipErrorInvalidValue;          // 32-bit per-lane element offsets (see z_load)
     hipLaunchKernelGGL(gram_kernel, dim3(8 * S * np), dim3(64 * NWV), 0, s, X, N, (int)M, ldX, y, slab, cr, S, np);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -159,3 +159,15 @@ def test_errors(partls):
     with pytest.raises(partls.PartlsError) as ei:
         partls.fit(partls.Opt, Xn, y, np.array([[1, 0], [1, 0], [0, 1]]))
     assert ei.value.status == partls.lowlevel.ERR_NONFINITE
+    # limits of this build are refused up front, before any memory is touched: ldX < 2^30 (32-bit element offsets in the Gram
+    # kernel's loads), M <= 1022, K <= 39
+    import torch
+    d = torch.zeros(16, dtype=torch.float64, device="cuda")
+    ctx = partls.Context()
+    with pytest.raises(partls.PartlsError) as ei:
+        ctx.opt_prepare_device(d.data_ptr(), d.data_ptr(), 4, 3, 1 << 30, np.array([[1, 0], [1, 0], [0, 1]]))
+    assert ei.value.status == partls.lowlevel.ERR_UNSUPPORTED
+    with pytest.raises(partls.PartlsError) as ei:
+        ctx.opt_prepare_device(d.data_ptr(), d.data_ptr(), 4, 3, 3, np.array([[1, 0], [1, 0], [0, 1]]))          # ldX < N
+    assert ei.value.status == partls.lowlevel.ERR_BAD_ARG
+    ctx.close()
