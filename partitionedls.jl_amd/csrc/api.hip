@@ -191,7 +191,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
     const bool coop = !c->use_reg && cnt == 1 && !c->knobs.no_coop;
     if (coop) {
-        const size_t need = ((size_t)ld * ld + (size_t)n / 8 + 2) * sizeof(double);      // tableau + basis flags
+        const size_t need = ((size_t)2 * ld * ld + (size_t)n / 8 + 2) * sizeof(double);  // two tableau images + basis flags + current image
         if (c->scratch.bytes < need) c->coop_state_valid = false;
         PARTLS_HIP_CHECK(c->scratch.ensure(need));
     } else {
@@ -243,7 +243,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     } else {
         PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
     }
-    unsigned long long counters[2] = {0, 0};
+    unsigned long long counters[4] = {0, 0, 0, 0};                 // unconverged, pivots, vetoes, (cooperative kernel) blocks
     PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->nodeSol.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(obj2.data(), c->nodeObj.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
@@ -253,6 +253,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (unconv) *unconv = counters[0];
+    c->last_pivots = counters[1]; c->last_vetoes = counters[2]; c->last_blocks = counters[3];
     c->tab_valid = dump && counters[0] == 0;
     return PARTLS_OK;
 }

@@ -86,7 +86,7 @@ struct partls_ctx {
     std::vector<uint64_t> mask_tab;
     bool use_reg = false;
     double tol = 0.0;
-    unsigned long long last_pivots = 0, last_vetoes = 0;
+    unsigned long long last_pivots = 0, last_vetoes = 0, last_blocks = 0;
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
     // final tableau of the last single-node solve on the register kernel (pinned host copies; see solve_nodes `want_tab`)
     double *hTab = nullptr;

@@ -8,6 +8,7 @@
 // overwrites the rows / columns of the pivoted variables from the final panel.  Block-local barriers only.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace partls {
 
@@ -16,113 +17,176 @@ static constexpr int GJ_MB = 16;              // pivots per block at most
 template <int NT>
 __device__ __forceinline__ void gj_panel_load(const double *T, int ld, const int *ks, int m, double *Pn, int tid)
 {
-    for (int j = 0; j < m; ++j) {
-        const double *src = T + (size_t)ks[j] * ld;
-        for (int i = tid; i < ld; i += NT) Pn[(size_t)j * ld + i] = __builtin_nontemporal_load(&src[i]);
+    // all m row loads of a thread are issued before the first LDS store: in the cooperative kernel the rows were just rewritten by
+    // other XCDs and come from memory (~2 us each) — one exposed latency per block instead of one per pivot row
+    for (int i = tid; i < ld; i += NT) {
+        double v[GJ_MB];
+#pragma unroll
+        for (int j = 0; j < GJ_MB; ++j) v[j] = (j < m) ? __builtin_nontemporal_load(&T[(size_t)ks[j] * ld + i]) : 0.0;
+#pragma unroll
+        for (int j = 0; j < GJ_MB; ++j) if (j < m) Pn[(size_t)j * ld + i] = v[j];
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ double gj_rcp(double d)       // v_rcp_f64 + two Newton steps (as sweep_blk.hip's fast_rcp): ~1 ulp
+{
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return y;
 }
 
 // returns the number of accepted pivots (uniform).  Acceptance of an ENTERING variable k follows the leave-one-out rule of
 // sweep_blk.hip: d_k > piv_eps and d_k > piv_eps * T[j][k]^2 for every variable row j — the basis B + k must not be
 // numerically dependent at the piv_eps level in ANY of its members (an exactly dependent column next to a nearly collinear
-// pair passes the first test alone: its computed pivot carries an error of eps * |c|^2).  s_basic is kept live here: the flag of
-// an accepted pivot flips at the end of its step (the callers only record the rejections).  red: NT / 64 doubles of scratch.
+// pair passes the first test alone: its computed pivot carries an error of eps * |c|^2).  Every row tests its own entry (a
+// nonbasic row satisfies T_jk^2 <= d_k, so only a basic row can trip it) and raises a flag in LDS — no reduction.  s_basic is
+// kept live here: the flag of an accepted pivot flips at the end of its step (the callers only record the rejections).
+// red: >= 2 doubles of scratch (the veto flags of even / odd steps).
+// Cost matters: the cooperative kernel runs this REDUNDANTLY in every workgroup, 16 sequential steps per block — the first version
+// (a max-reduction per step through shuffles and LDS, a runtime-bounded column loop whose LDS round trips could not overlap)
+// took 3 us per step, 49 of the 82 us of a block at n = 513 (stamped).
 template <int NT>
-__device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double *dinv, double *uj, double *red, const int *ks, int m,
-                                                  int ld, uint8_t *s_basic, double piv_eps, int tid)
+__device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double *dinv, double *uj, double *red, const int *ks, int m_,
+                                                  int ld_, uint8_t *s_basic, double piv_eps, int tid)
 {
+    // everything that steers control flow is made provably wave-uniform (it comes from LDS words or arguments the compiler cannot
+    // see through): scalar branches and scalar address arithmetic instead of exec masks and per-lane 64-bit index math
+    const int m = __builtin_amdgcn_readfirstlane(m_), ld = __builtin_amdgcn_readfirstlane(ld_);
+    if (tid < 2) red[tid] = 0.0;
+    __syncthreads();
     int accepted = 0;
     for (int s = 0; s < m; ++s) {
-        const int k = ks[s];
-        // Two barriers per step.  Before the first: the entries of the pivot COLUMN s at the pivot rows are published (not of column j
-        // at row k: equal only in exact arithmetic — with the factor taken from column s the panel receives exactly the symmetric
-        // rank-1 term z_s z_s'/d_s of the fused update; mixing the two loses the solution on ill-conditioned data, see
-        // sweep_blk.hip), and every wave leaves its part of max_i T_ik^2 over the variable rows (nonbasic rows satisfy
-        // T_ik^2 <= d_k, so only a basic row can trip the leave-one-out test) — computed unconditionally: cheaper than a barrier.
-        if (tid < m) uj[tid] = Pn[(size_t)s * ld + ks[tid]];
-        double c2 = 0.0;
-        for (int i = tid; i < ld - 1; i += NT)
-            if (i != k) { const double z = Pn[(size_t)s * ld + i]; c2 = fmax(c2, z * z); }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c2 = fmax(c2, __shfl_xor(c2, off));
-        if ((tid & 63) == 0) red[tid >> 6] = c2;
-        __syncthreads();
-        const double d = uj[s];
-        const bool bas = s_basic[k] != 0;
-        bool ok = bas || (d > piv_eps);
-        if (ok && !bas) {                                                // uniform
-            double cmax2 = 0.0;
-            for (int w = 0; w < NT / 64; ++w) cmax2 = fmax(cmax2, red[w]);
-            ok = !(cmax2 * piv_eps >= d);
+        const int k = __builtin_amdgcn_readfirstlane(ks[s]);
+        double *Ps = Pn + s * ld;
+        const double d = Ps[k];                                          // column s is final since the previous step's closing barrier
+        const bool bas = __builtin_amdgcn_readfirstlane((int)s_basic[k]) != 0;
+        // entries of the pivot COLUMN s at the pivot rows (not of column j at row k: equal only in exact arithmetic — with the
+        // factor taken from column s the panel receives exactly the symmetric rank-1 term z_s z_s'/d_s of the fused update;
+        // mixing the two loses the solution on ill-conditioned data, see sweep_blk.hip)
+        if (tid < m) uj[tid] = Ps[ks[tid]];
+        if (!bas) {                                                      // an entering variable
+            bool trip = false;
+            for (int i = tid; i < ld - 1; i += NT)
+                if (i != k) { const double z = Ps[i]; trip = trip || ((z * z) * piv_eps >= d); }
+            if (trip) red[s & 1] = 1.0;                                  // same value from every writer
         }
-        const double inv = ok ? 1.0 / d : 0.0, ainv = fabs(inv);
+        __syncthreads();
+        const double flag = red[s & 1];
+        const bool ok = bas || (__builtin_amdgcn_readfirstlane((int)(d > piv_eps && flag == 0.0)) != 0);
+        if (tid == 0) red[(s + 1) & 1] = 0.0;                            // the other flag: last read before the previous closing barrier
+        const double inv = ok ? gj_rcp(d) : 0.0, ainv = fabs(inv);
         if (ok) {
             ++accepted;
             for (int i = tid; i < ld; i += NT) {
-                const double zi = Pn[(size_t)s * ld + i];
-                Zn[(size_t)s * ld + i] = zi;
+                const double zi = Ps[i];
+                Zn[s * ld + i] = zi;
                 const double mi = -zi * inv;
-                for (int j = 0; j < m; ++j) {
-                    if (j == s) continue;
-                    const double pji = Pn[(size_t)j * ld + i];
-                    Pn[(size_t)j * ld + i] = (i == k) ? uj[j] * ainv : fma(mi, uj[j], pji);
+                const bool piv = i == k;
+                // columns in groups of four: the four panel reads and the four pivot-row entries are in flight together (one LDS
+                // round trip per group, not per column).  Column s itself is processed like the others and overwritten below.
+                int j = 0;
+                for (; j + 4 <= m; j += 4) {
+                    double pj[4], u[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { pj[q] = Pn[(j + q) * ld + i]; u[q] = uj[j + q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Pn[(j + q) * ld + i] = piv ? u[q] * ainv : fma(mi, u[q], pj[q]);
                 }
-                Pn[(size_t)s * ld + i] = (i == k) ? -inv : zi * ainv;
+                for (; j < m; ++j) {
+                    const double pj = Pn[j * ld + i], u = uj[j];
+                    Pn[j * ld + i] = piv ? u * ainv : fma(mi, u, pj);
+                }
+                Ps[i] = piv ? -inv : zi * ainv;
             }
         }
         if (tid == 0) dinv[s] = inv;
-        __syncthreads();                                                 // panel, uj, red and the old basis flag are done with
+        __syncthreads();                                                 // panel, uj, the flag and the old basis flag are done with
         if (ok && tid == 0) s_basic[k] ^= 1;                             // the next read of THIS flag is behind a later barrier
     }
     __syncthreads();
     return accepted;
 }
 
-// fused rank-m update of rows [row0, row1) (one wave per row), then the pivoted rows / columns from the final panel
+// fused rank-m update of rows [row0, row1), then the pivoted rows / columns from the final panel.  One wave per row, or two (each
+// half of the columns) when the workgroup owns so few rows that half its waves would idle (the cooperative kernel at n = 513: 9
+// rows for 16 waves).  A row is walked in spans of 8 x 64 columns — eight global loads in flight, then per accepted pivot as many LDS
+// reads and FMAs — and one last span of the remaining 1..8 chunks (its own instantiation per length: straight-line code); which pivots of the block were accepted is a wave-uniform bit mask.
+// Tsrc == nullptr: in place (sweep_generic.hip).  Otherwise the rows are read from Tsrc and written to T — the cooperative kernel
+// ping-pongs between two tableau images so that nobody rewrites a row that another workgroup may still be loading.
 template <int NT>
-__device__ __forceinline__ void gj_apply(double *T, int ld, int row0, int row1, const double *Pn, const double *Zn, const double *dinv,
-                                         const int *ks, int m, int tid)
+__device__ __forceinline__ void gj_apply(double *T, int ld_, int row0_, int row1_, const double *Pn, const double *Zn, const double *dinv,
+                                         const int *ks, int m_, int tid, const double *Tsrc = nullptr)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    // Each wave owns whole rows; the row is walked in chunks of 8 x 64 columns with all eight loads issued before the first
-    // use: a single workgroup per CU has little memory-level parallelism otherwise (one dependent HBM latency per 64 elements).
-    constexpr int U = 8;
-    for (int i = row0 + wave; i < row1; i += NT / 64) {
+    if (!Tsrc) Tsrc = T;
+    constexpr int NWAVES = NT / 64;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = __builtin_amdgcn_readfirstlane(m_), ld = __builtin_amdgcn_readfirstlane(ld_);
+    const int row0 = __builtin_amdgcn_readfirstlane(row0_), row1 = __builtin_amdgcn_readfirstlane(row1_);
+    unsigned act = 0;                                                       // accepted pivots of the block (a rejected one never wrote Zn[s])
+    for (int s = 0; s < m; ++s) if (dinv[s] != 0.0) act |= 1u << s;
+    act = (unsigned)__builtin_amdgcn_readfirstlane((int)act);
+    const int nrows = row1 - row0;
+    const int split = (2 * nrows <= NWAVES) ? 2 : 1;
+    const int hs = (((ld + 1) / 2 + 63) / 64) * 64;                         // first half [0, hs), second [hs, ld)
+    for (int it = wave; it < nrows * split; it += NWAVES) {
+        const int i = row0 + it / split, half = it % split;
+        const int cbeg = half ? hs : 0, cend = (split == 2 && !half) ? (hs < ld ? hs : ld) : ld;
         double *row = T + (size_t)i * ld;
+        const double *srow = Tsrc + (size_t)i * ld;
         double fi[GJ_MB];
 #pragma unroll
-        for (int s = 0; s < GJ_MB; ++s) fi[s] = (s < m && dinv[s] != 0.0) ? -Zn[(size_t)s * ld + i] * dinv[s] : 0.0;   // rejected pivot: Zn[s] was never written
-        for (int c0 = lane; c0 < ld; c0 += 64 * U) {
+        for (int s = 0; s < GJ_MB; ++s) fi[s] = ((act >> s) & 1u) ? -Zn[s * ld + i] * dinv[s] : 0.0;
+        int c0 = cbeg;
+        // a span of U x 64 columns with all its loads in flight together; LAST: its final chunk may be partial (lane predicate)
+        auto span = [&](auto uc, auto lastc) {
+            constexpr int U = decltype(uc)::value;
+            constexpr bool LAST = decltype(lastc)::value;
+            const int cl = c0 + 64 * (U - 1) + lane;
+            const bool vl = !LAST || cl < cend;
             double acc[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int c = c0 + 64 * u;
-                acc[u] = (c < ld) ? __builtin_nontemporal_load(&row[c]) : 0.0;
+                if (LAST && u == U - 1) acc[u] = vl ? __builtin_nontemporal_load(&srow[cl]) : 0.0;
+                else acc[u] = __builtin_nontemporal_load(&srow[c0 + 64 * u + lane]);
             }
 #pragma unroll
             for (int s = 0; s < GJ_MB; ++s) {
-                if (s < m && dinv[s] != 0.0) {
+                if ((act >> s) & 1u) {                                      // scalar branch
+                    double z[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c = c0 + 64 * u;
-                        acc[u] = fma(fi[s], Zn[(size_t)s * ld + (c < ld ? c : 0)], acc[u]);
-                    }
+                    for (int u = 0; u < U; ++u) z[u] = Zn[s * ld + ((LAST && u == U - 1) ? (vl ? cl : cbeg) : c0 + 64 * u + lane)];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u] = fma(fi[s], z[u], acc[u]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int c = c0 + 64 * u;
-                if (c < ld) row[c] = acc[u];
+                if (LAST && u == U - 1) { if (vl) row[cl] = acc[u]; }
+                else row[c0 + 64 * u + lane] = acc[u];
             }
+        };
+        using std::integral_constant;
+        for (; c0 + 512 < cend; c0 += 512) span(integral_constant<int, 8>{}, std::false_type{});
+        switch ((cend - c0 + 63) >> 6) {                                    // the rest of the row (1..8 chunks) as ONE span: scalar jump
+            case 1: span(integral_constant<int, 1>{}, std::true_type{}); break;
+            case 2: span(integral_constant<int, 2>{}, std::true_type{}); break;
+            case 3: span(integral_constant<int, 3>{}, std::true_type{}); break;
+            case 4: span(integral_constant<int, 4>{}, std::true_type{}); break;
+            case 5: span(integral_constant<int, 5>{}, std::true_type{}); break;
+            case 6: span(integral_constant<int, 6>{}, std::true_type{}); break;
+            case 7: span(integral_constant<int, 7>{}, std::true_type{}); break;
+            case 8: span(integral_constant<int, 8>{}, std::true_type{}); break;
+            default: break;
         }
     }
     __syncthreads();                                                       // all generic updates of this workgroup are issued
     for (int j = 0; j < m; ++j) {
-        const int k = ks[j];
-        for (int i = row0 + tid; i < row1; i += NT) T[(size_t)i * ld + k] = Pn[(size_t)j * ld + i];           // column k
+        const int k = __builtin_amdgcn_readfirstlane(ks[j]);
+        for (int i = row0 + tid; i < row1; i += NT) T[(size_t)i * ld + k] = Pn[j * ld + i];                   // column k
         if (k >= row0 && k < row1)
-            for (int c = tid; c < ld; c += NT) T[(size_t)k * ld + c] = Pn[(size_t)j * ld + c];               // row k
+            for (int c = tid; c < ld; c += NT) T[(size_t)k * ld + c] = Pn[j * ld + c];                       // row k
     }
     __syncthreads();
 }

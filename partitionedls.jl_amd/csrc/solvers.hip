@@ -93,6 +93,7 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         st = solve_nodes(c, codes, 1, sols, obj2, &unconv, /*resume=*/i > 1);   // warm start after the first α-step
         const auto tt1 = std::chrono::steady_clock::now();
         if (st != PARTLS_OK) return st;
+        const unsigned long long apiv = c->last_pivots, ablk = c->last_blocks;
         unconv_total += unconv;
         std::vector<double> wv;
         unscale_solution(c, sols.data(), wv);
@@ -140,7 +141,7 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         }
         oldopt = optval;
         optval = std::sqrt(o2 > 0.0 ? o2 : 0.0);
-        if (c->knobs.alt_trace) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms, rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
+        if (c->knobs.alt_trace) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms (%llu pivots, %llu blocks), rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), apiv, ablk, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
         ++i;
     }
     w_from();

@@ -13,8 +13,10 @@
 //                barriers only; column s as of its own step is kept in Z[s][.], 1/d_s in dinv[s] (0 = rejected as dependent);
 //   3. update  : each workgroup applies the fused rank-m update T_ic -= sum_s Z_s[i] Z_s[c] / d_s to ITS rows, then overwrites
 //                the rows / columns of the pivoted variables from the final panel;
-//   4. one grid barrier (plus one between 1 and 3: the panel copies must be complete before any owner rewrites a pivot row).
-// So the grid synchronises twice per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables).
+//   4. ONE grid barrier.  The update reads image `cur` of the tableau and writes image `cur ^ 1` (every row has exactly one owner,
+//      so the other image is complete after the barrier): nobody rewrites a row that a slower workgroup may still be loading into
+//      its panel or scanning, which in the in-place form needed a second grid barrier per block (~10 us each at 64 workgroups).
+// So the grid synchronises once per block instead of twice per pivot (the first α-step of Alt at C4 exchanges ~250 variables in 17 blocks).
 //
 // Grid barrier.  An ordinary launch with a hand-written barrier on a monotone global counter (release add / acquire poll at
 // agent scope), not hipLaunchCooperativeKernel: the runtime's cooperative queue cost ~7 ms on its first use in a process and,
@@ -32,23 +34,28 @@ namespace partls {
 // with n_unconverged poisoned so that the host reports an error instead of hanging the device.
 __device__ __forceinline__ bool grid_barrier(unsigned *ctr, unsigned nwg, unsigned &epoch, int *s_ok)
 {
-    __syncthreads();                                               // every wave's stores are issued ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave's stores have left the wave ...
+    __syncthreads();
     if (threadIdx.x == 0) {
         epoch += nwg;
-        __threadfence();                                           // ... and visible at agent scope before the arrival
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // One release before the arrival and ONE acquire after the poll (MI355X_MICROARCH.md: an agent release writes back this
+        // XCD's dirty L2 lines, ~1.7-6.5 us; an agent acquire invalidates this CU's L1, ~1.7 us; a __threadfence() is both, and
+        // polling with acquire loads is 2-3x slower per hop than a relaxed poll followed by one fence).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");         // ... and are visible at agent scope before the arrival;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the compiler may drop the wait behind the write-back (ROCm 7.2)
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 26)) { *s_ok = 0; break; }
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 27)) { *s_ok = 0; break; }
         }
-        __threadfence();                                           // acquire: drops this CU's stale L1 lines
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drops this CU's stale L1 lines (and the other XCDs' lines in L2)
     }
     __syncthreads();
     return *s_ok != 0;
 }
 
-static constexpr int COOP_THREADS = 1024;  // 16 waves per CU: the fused update is bound by memory latency, not by issue
+static constexpr int COOP_THREADS = 1024;  // 16 waves per CU (512 threads, spill-free, is slower: 1.63 vs 1.39 ms per alpha-step at C4)
 static constexpr int COOP_MAXWORDS = 16;
 static constexpr int COOP_MB = GJ_MB;
 
@@ -72,24 +79,26 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
     __shared__ int s_ok;                                           // 0 after a grid-barrier timeout
     if (threadIdx.x == 0) s_ok = 1;
 
-    double *T = p.scratch;
+    double *Timg[2] = {p.scratch, p.scratch + (size_t)ld * ld};    // two tableau images (ping-pong, see the file header)
     const int nwg = gridDim.x, wg = blockIdx.x;
     const int rows_per = (ld + nwg - 1) / nwg;
     const int row0 = wg * rows_per, row1 = (row0 + rows_per < ld) ? row0 + rows_per : ld;
     const int nwords = (n + 63) >> 6;
 
-    uint8_t *flagbuf = reinterpret_cast<uint8_t *>(T + (size_t)ld * ld);       // basis flags kept across launches
+    uint8_t *flagbuf = reinterpret_cast<uint8_t *>(p.scratch + (size_t)2 * ld * ld);   // basis flags + current image, kept across launches
+    int cur = 0;
     if (!p.resume) {
         for (int i = row0 + wave; i < row1; i += COOP_THREADS / 64)
-            for (int j = lane; j < ld; j += 64) T[(size_t)i * ld + j] = p.T0[(size_t)i * ld + j];
+            for (int j = lane; j < ld; j += 64) Timg[0][(size_t)i * ld + j] = p.T0[(size_t)i * ld + j];
         for (int i = tid; i < n; i += COOP_THREADS) { s_basic[i] = 0; s_blocked[i] = 0; }
     } else {
         for (int i = tid; i < n; i += COOP_THREADS) { s_basic[i] = flagbuf[i]; s_blocked[i] = 0; }
+        cur = flagbuf[n] & 1;
     }
     const int8_t *code = p.node_code;                              // one node: per-variable constraint codes
     if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
 
-    unsigned long long npiv = 0, nunconv = 0;
+    unsigned long long npiv = 0, nunconv = 0, nblk = 0;
     int ninf_best = n + 1, patience = 3, rounds = 0;
     bool progress = false;
     for (;;) {
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             const int v = base + tid;
             bool bad = false;
             if (v < n) {
-                const double q = __builtin_nontemporal_load(&T[(size_t)n * ld + v]);
+                const double q = __builtin_nontemporal_load(&Timg[cur][(size_t)n * ld + v]);
                 const int cd = (int)code[v];
                 const int f = cd == 2 ? 0 : cd;
                 const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
@@ -137,31 +146,32 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             const int m = (nv - b0 < mb) ? nv - b0 : mb;
             const int *ks = s_viol + b0;
             // ---- 1. panel, 2. redundant elimination (block-local barriers only), 3. fused update of the owned rows ------------
-            gj_panel_load<COOP_THREADS>(T, ld, ks, m, Pn, tid);
-            // every workgroup has its copy of the pivot rows (and has finished the KKT scan of the rhs row) before any owner
-            // rewrites them: without this barrier a fast workgroup's update races with a slow one's panel load
-            if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
+            gj_panel_load<COOP_THREADS>(Timg[cur], ld, ks, m, Pn, tid);
             gj_panel_eliminate<COOP_THREADS>(Pn, Zn, dinv, uj, red, ks, m, ld, s_basic, p.piv_eps, tid);
-            gj_apply<COOP_THREADS>(T, ld, row0, row1, Pn, Zn, dinv, ks, m, tid);
+            gj_apply<COOP_THREADS>(Timg[cur ^ 1], ld, row0, row1, Pn, Zn, dinv, ks, m, tid, Timg[cur]);
             if (tid == 0) {
                 for (int j = 0; j < m; ++j) {
                     if (dinv[j] == 0.0) s_blocked[ks[j]] = 1;                // accepted pivots flipped s_basic in the panel
                 }
             }
             for (int j = 0; j < m; ++j) if (dinv[j] != 0.0) { progress = true; ++npiv; }
-            // the whole tableau is updated before anybody reads it again (agent-scope release / acquire inside: per-XCD L2s are not coherent)
+            ++nblk;
+            cur ^= 1;
+            // the other image is complete before anybody reads it (agent-scope release / acquire inside: per-XCD L2s are not coherent)
             if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
         }
     }
     if (wg == 0) {
         for (int i = tid; i < n; i += COOP_THREADS) flagbuf[i] = s_basic[i];
         for (int i = tid; i < n; i += COOP_THREADS)
-            p.node_sol[i] = s_basic[i] ? __builtin_nontemporal_load(&T[(size_t)n * ld + i]) : 0.0;
+            p.node_sol[i] = s_basic[i] ? __builtin_nontemporal_load(&Timg[cur][(size_t)n * ld + i]) : 0.0;
         if (tid == 0) {
-            p.node_obj2[0] = __builtin_nontemporal_load(&T[(size_t)n * ld + n]);
+            flagbuf[n] = (uint8_t)cur;
+            p.node_obj2[0] = __builtin_nontemporal_load(&Timg[cur][(size_t)n * ld + n]);
             p.best_obj[0] = 0.0; p.best_pat[0] = 0;
             if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
             if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
+            if (p.n_pivots && nblk) atomicAdd(p.n_pivots + 2, nblk);          // counters[3]: blocks (diagnostic, PARTLS_ALT_TRACE)
         }
     }
 }
