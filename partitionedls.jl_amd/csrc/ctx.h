@@ -50,6 +50,7 @@ struct partls_knobs {
     long long chain_len = 0;     // PARTLS_CHAIN_LEN: patterns per Gray chain (0 = automatic)
     long long grid = 0;          // PARTLS_GRID: workgroups of the sweep (0 = automatic)
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
+    int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE

@@ -43,10 +43,13 @@ __device__ __forceinline__ double gj_rcp(double d)       // v_rcp_f64 + two Newt
 // pair passes the first test alone: its computed pivot carries an error of eps * |c|^2).  Every row tests its own entry (a
 // nonbasic row satisfies T_jk^2 <= d_k, so only a basic row can trip it) and raises a flag in LDS — no reduction.  s_basic is
 // kept live here: the flag of an accepted pivot flips at the end of its step (the callers only record the rejections).
-// red: >= 2 doubles of scratch (the veto flags of even / odd steps).
-// Cost matters: the cooperative kernel runs this REDUNDANTLY in every workgroup, 16 sequential steps per block — the first version
-// (a max-reduction per step through shuffles and LDS, a runtime-bounded column loop whose LDS round trips could not overlap)
-// took 3 us per step, 49 of the 82 us of a block at n = 513 (stamped).
+// Layout, as in sweep_blk.hip: thread t keeps ROW t of the panel in registers for the whole block (NT >= ld: one row per
+// thread); a step exchanges only the m pivot-row entries of its pivot column through LDS (uj, double buffered: the owners
+// publish the entries of column s+1 at the end of step s) and stores column s as of its own step to Zn.  Two barriers per step.
+// uj: 2 x GJ_MB doubles, red: >= 2 doubles (the veto flags of even / odd steps).
+// Cost matters: the cooperative kernel runs this REDUNDANTLY in every workgroup, 16 sequential steps per block.  History at
+// n = 513 (stamped, cycles per step): 6.8k with a max-reduction per step and a runtime-bounded column loop on the LDS panel
+// (49 of the 82 us of a block), 3.9k with uniform control flow and grouped LDS reads, now ~1k.
 template <int NT>
 __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double *dinv, double *uj, double *red, const int *ks, int m_,
                                                   int ld_, uint8_t *s_basic, double piv_eps, int tid)
@@ -54,24 +57,28 @@ __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double
     // everything that steers control flow is made provably wave-uniform (it comes from LDS words or arguments the compiler cannot
     // see through): scalar branches and scalar address arithmetic instead of exec masks and per-lane 64-bit index math
     const int m = __builtin_amdgcn_readfirstlane(m_), ld = __builtin_amdgcn_readfirstlane(ld_);
+    const bool has_row = tid < ld;
+    const bool var_row = tid < ld - 1;                                   // the last row is the rhs: no variable, never vetoes
+    double pv[GJ_MB];
+#pragma unroll
+    for (int j = 0; j < GJ_MB; ++j) pv[j] = (j < m && has_row) ? Pn[j * ld + tid] : 0.0;
+    int myj = -1;                                                        // this row is pivot row myj of the block
+    for (int j = 0; j < m; ++j) if (ks[j] == tid) myj = j;
+    if (myj >= 0) uj[myj] = pv[0];                                       // entries of pivot column 0 at the pivot rows
     if (tid < 2) red[tid] = 0.0;
     __syncthreads();
     int accepted = 0;
-    for (int s = 0; s < m; ++s) {
+#pragma unroll
+    for (int s = 0; s < GJ_MB; ++s) {
+        if (s >= m) break;                                               // uniform
         const int k = __builtin_amdgcn_readfirstlane(ks[s]);
-        double *Ps = Pn + s * ld;
-        const double d = Ps[k];                                          // column s is final since the previous step's closing barrier
-        const bool bas = __builtin_amdgcn_readfirstlane((int)s_basic[k]) != 0;
+        const double *us = uj + (s & 1) * GJ_MB;
         // entries of the pivot COLUMN s at the pivot rows (not of column j at row k: equal only in exact arithmetic — with the
         // factor taken from column s the panel receives exactly the symmetric rank-1 term z_s z_s'/d_s of the fused update;
         // mixing the two loses the solution on ill-conditioned data, see sweep_blk.hip)
-        if (tid < m) uj[tid] = Ps[ks[tid]];
-        if (!bas) {                                                      // an entering variable
-            bool trip = false;
-            for (int i = tid; i < ld - 1; i += NT)
-                if (i != k) { const double z = Ps[i]; trip = trip || ((z * z) * piv_eps >= d); }
-            if (trip) red[s & 1] = 1.0;                                  // same value from every writer
-        }
+        const double d = us[s];
+        const bool bas = __builtin_amdgcn_readfirstlane((int)s_basic[k]) != 0;
+        if (!bas && var_row && tid != k && (pv[s] * pv[s]) * piv_eps >= d) red[s & 1] = 1.0;   // same value from every writer
         __syncthreads();
         const double flag = red[s & 1];
         const bool ok = bas || (__builtin_amdgcn_readfirstlane((int)(d > piv_eps && flag == 0.0)) != 0);
@@ -79,32 +86,26 @@ __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double
         const double inv = ok ? gj_rcp(d) : 0.0, ainv = fabs(inv);
         if (ok) {
             ++accepted;
-            for (int i = tid; i < ld; i += NT) {
-                const double zi = Ps[i];
-                Zn[s * ld + i] = zi;
-                const double mi = -zi * inv;
-                const bool piv = i == k;
-                // columns in groups of four: the four panel reads and the four pivot-row entries are in flight together (one LDS
-                // round trip per group, not per column).  Column s itself is processed like the others and overwritten below.
-                int j = 0;
-                for (; j + 4 <= m; j += 4) {
-                    double pj[4], u[4];
+            const double zi = pv[s];
+            if (has_row) Zn[s * ld + tid] = zi;
+            const double mi = -zi * inv;
+            const bool piv = tid == k;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { pj[q] = Pn[(j + q) * ld + i]; u[q] = uj[j + q]; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Pn[(j + q) * ld + i] = piv ? u[q] * ainv : fma(mi, u[q], pj[q]);
+            for (int j = 0; j < GJ_MB; ++j) {
+                if (j < m && j != s) {                                   // uniform
+                    const double u = us[j];
+                    pv[j] = piv ? u * ainv : fma(mi, u, pv[j]);
                 }
-                for (; j < m; ++j) {
-                    const double pj = Pn[j * ld + i], u = uj[j];
-                    Pn[j * ld + i] = piv ? u * ainv : fma(mi, u, pj);
-                }
-                Ps[i] = piv ? -inv : zi * ainv;
             }
+            pv[s] = piv ? -inv : zi * ainv;
         }
         if (tid == 0) dinv[s] = inv;
-        __syncthreads();                                                 // panel, uj, the flag and the old basis flag are done with
+        if (s + 1 < GJ_MB) { if (s + 1 < m && myj >= 0) uj[((s + 1) & 1) * GJ_MB + myj] = pv[s + 1]; }   // pivot column s+1 at the pivot rows
+        __syncthreads();                                                 // uj, the flag and the old basis flag are done with
         if (ok && tid == 0) s_basic[k] ^= 1;                             // the next read of THIS flag is behind a later barrier
     }
+#pragma unroll
+    for (int j = 0; j < GJ_MB; ++j) if (j < m && has_row) Pn[j * ld + tid] = pv[j];     // the final panel: rows / columns of the pivoted variables
     __syncthreads();
     return accepted;
 }

@@ -69,8 +69,8 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
     double *Pn = smem;                                            // [mb][ld] panel: the block's pivot columns, all rows
     double *Zn = Pn + (size_t)mb * ld;                            // [mb][ld] column s as of its own step
     double *dinv = Zn + (size_t)mb * ld;                          // [COOP_MB] 1/d_s (0: rejected)
-    double *uj = dinv + COOP_MB;                                  // [COOP_MB] pivot-row entries of the current step
-    double *red = uj + COOP_MB;                                   // [COOP_THREADS / 64] reduction scratch
+    double *uj = dinv + COOP_MB;                                  // [2][COOP_MB] pivot-row entries of the current / next step
+    double *red = uj + 2 * COOP_MB;                                   // [COOP_THREADS / 64] reduction scratch
     uint8_t *s_basic = reinterpret_cast<uint8_t *>(red + COOP_THREADS / 64);
     uint8_t *s_blocked = s_basic + n;
     __shared__ unsigned long long s_inf[COOP_MAXWORDS];
@@ -181,7 +181,7 @@ hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s)
     const int ld = p.n + 1;
     // pivots per block: two [mb][ld] LDS images within ~136 KB
     int mb = gj_block_size(ld, (size_t)136 * 1024);
-    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + (2 * COOP_MB + COOP_THREADS / 64) * sizeof(double) + 2 * (size_t)p.n + 16;
+    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + (3 * COOP_MB + COOP_THREADS / 64) * sizeof(double) + 2 * (size_t)p.n + 16;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_coop_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;

@@ -38,8 +38,8 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
     double *Pn = smem;                                            // [mb][ld] panel: the block's pivot columns, all rows
     double *Zn = Pn + (size_t)mb * ld;                            // [mb][ld] column s as of its own step
     double *dinv = Zn + (size_t)mb * ld;                          // [GJ_MB] 1/d_s (0: rejected)
-    double *uj = dinv + GJ_MB;                                    // [GJ_MB] pivot-row entries of the current step
-    double *red = uj + GJ_MB;                                     // [GEN_THREADS / 64] reduction scratch
+    double *uj = dinv + GJ_MB;                                    // [2][GJ_MB] pivot-row entries of the current / next step
+    double *red = uj + 2 * GJ_MB;                                     // [GEN_THREADS / 64] reduction scratch
     uint8_t *s_basic = reinterpret_cast<uint8_t *>(red + GEN_THREADS / 64);   // n bytes
     uint8_t *s_blocked = s_basic + n;                             // n bytes
     __shared__ unsigned long long s_inf[GEN_MAXWORDS];
@@ -155,7 +155,7 @@ hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s)
 {
     const int ld = p.n + 1;
     int mb = gj_block_size(ld, (size_t)136 * 1024);
-    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + (2 * GJ_MB + GEN_THREADS / 64) * sizeof(double) + 2 * (size_t)p.n + 16;
+    const size_t shmem = (size_t)2 * mb * ld * sizeof(double) + (3 * GJ_MB + GEN_THREADS / 64) * sizeof(double) + 2 * (size_t)p.n + 16;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_generic_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return e;
