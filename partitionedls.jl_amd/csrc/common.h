@@ -92,7 +92,6 @@ hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, c
 hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *g,
                       hipStream_t s);
 hipError_t launch_synth(uint64_t seed, int64_t N, int64_t D, const double *wstar_dev, double *X, double *y, hipStream_t s);
-hipError_t launch_finite_check(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int *flag, hipStream_t s);
 
 // host-side mirror of the device generator (synth.hip); also used by partls_synth_truth
 uint64_t rnd64(uint64_t seed, uint64_t stream, uint64_t idx);

@@ -59,28 +59,6 @@ hipError_t launch_synth(uint64_t seed, int64_t N, int64_t D, const double *wstar
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// NaN/Inf screen of the inputs (PARTLS_ERR_NONFINITE)
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ void finite_check_kernel(const double *__restrict__ X, int64_t N, int64_t M, int64_t ldX,
-                                    const double *__restrict__ y, int *flag)
-{
-    const int64_t total = N * (M + 1);
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = i / N, r = i - c * N;
-        const double v = (c < M) ? X[r + c * ldX] : y[r];
-        bad |= !isfinite(v);
-    }
-    if (bad) atomicExch(flag, 1);
-}
-
-hipError_t launch_finite_check(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int *flag, hipStream_t s)
-{
-    hipLaunchKernelGGL(finite_check_kernel, dim3(2048), dim3(256), 0, s, X, N, M, ldX, y, flag);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Tableau preparation.  Input: G_aug ((M+2)^2, variables [features, intercept, y]).
 //   1. regularisation, PartitionedLS.jl:108-123 in Gram form: G[a][b] += eta * #(groups containing both a and b)
 //      (the K' extra rows sqrt(eta)*1_{group k}; y is padded with zeros so c and yy are unchanged);

@@ -159,6 +159,15 @@ def test_errors(partls):
     with pytest.raises(partls.PartlsError) as ei:
         partls.fit(partls.Opt, Xn, y, np.array([[1, 0], [1, 0], [0, 1]]))
     assert ei.value.status == partls.lowlevel.ERR_NONFINITE
+    for bad_y in (np.inf, -np.inf, np.nan):                      # the screen is the Gram diagonal (sum of squares per column of [X y])
+        yn = y.copy(); yn[2] = bad_y
+        with pytest.raises(partls.PartlsError) as ei:
+            partls.fit(partls.Opt, X, yn, np.array([[1, 0], [1, 0], [0, 1]]))
+        assert ei.value.status == partls.lowlevel.ERR_NONFINITE
+    Xi = X.copy(); Xi[3, 0] = -np.inf
+    with pytest.raises(partls.PartlsError) as ei:
+        partls.fit(partls.Alt, Xi, y, np.array([[1, 0], [1, 0], [0, 1]]))
+    assert ei.value.status == partls.lowlevel.ERR_NONFINITE
     # limits of this build are refused up front, before any memory is touched: ldX < 2^30 (32-bit element offsets in the Gram
     # kernel's loads), M <= 1022, K <= 39
     import torch
