@@ -145,9 +145,14 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         ++i;
     }
     w_from();
+    // Final objective.  The loss of the last iteration, beta'H beta - 2 g'beta + y'y from the K' x K' system, carries an absolute error
+    // of ~eps * y'y (cancellation against y'y): relative to opt^2 that is below 1e-10 as long as opt^2 > 1e-6 * y'y, and then it IS
+    // the result; only a near-interpolating fit (the reference's toy: opt = 0) pays the extra pass over X (0.87 ms of 4.1 GB at C4).
     double dopt = optval;
-    st = data_objective(c, w, &dopt);                    // final objective from the data (no Gram cancellation)
-    if (st != PARTLS_OK) return st;
+    if (!(optval * optval > 1e-6 * h_reg(c, Y, Y))) {
+        st = data_objective(c, w, &dopt);                // from the data: no Gram cancellation
+        if (st != PARTLS_OK) return st;
+    }
     for (int64_t m = 0; m < M; ++m) alpha[m] = a[(size_t)m];
     for (int64_t k = 0; k < K; ++k) beta[k] = b[(size_t)k];
     *t = b[(size_t)K] * a[(size_t)M];                    // Alt.jl:119
