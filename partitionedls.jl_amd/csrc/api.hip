@@ -564,10 +564,24 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     }
     const int n = c->n, ld = n + 1;
     const int64_t total = g_end - g_begin;
-    int64_t chain_len = c->knobs.chain_len > 0 ? c->knobs.chain_len : (c->use_reg ? 1024 : 64);   // a chain start costs ~8 patterns' pivots
+    // Chain length.  A chain start costs ~8 patterns' pivots, so chains should be long (~1024 patterns), but the register kernel runs ONE
+    // chain per CU at a time and the chains of a range take almost equally long: the sweep lasts ceil(chains / CUs) chain times, and a
+    // chain count that is not a multiple of the CU count pays for the whole last round (measured on C3, 256 CUs: 1024 chains of 1024
+    // patterns 74.9 ms, 768 of 1366 75.1, but 820 of 1280 90.6 and 1366 of 768 81.5).  So: a whole number k >= 2 of chains per CU.
+    int64_t chain_len;
+    if (c->knobs.chain_len > 0) chain_len = c->knobs.chain_len;
+    else if (c->use_reg) {
+        int ncu = 256;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+        int64_t k = (total + (int64_t)ncu * 1024 - 1) / ((int64_t)ncu * 1024);
+        if (k < 2) k = 2;
+        chain_len = (total + k * ncu - 1) / (k * ncu);
+        if (chain_len < 16) chain_len = 16;                     // tiny ranges: fewer chains than CUs rather than chains of a few patterns
+    } else {
+        chain_len = 64;
+        while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
+    }
     if (chain_len < 1) chain_len = 1;
-    // keep every CU busy on small problems: at least ~2 chains per CU when there are enough patterns
-    while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
     const int64_t nchains = (total + chain_len - 1) / chain_len;
     if (nchains >= (1LL << 31) || chain_len >= (1LL << 31)) { set_error("partls_opt_sweep: more than 2^31 chains in one call; split the Gray-index range"); return PARTLS_ERR_UNSUPPORTED; }
     int grid = (int)std::min<int64_t>(nchains, c->knobs.grid > 0 ? c->knobs.grid : (c->use_reg ? 4096 : 1024));
