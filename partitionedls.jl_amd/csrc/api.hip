@@ -313,7 +313,7 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     // Schur complement): delta_B = -D T_BB D rhs is one p x p matrix-vector product per step instead of a p^3/6 factorisation.
     // Valid when the basis IS the support (a basic variable that came out exactly 0 would not be in `sup`): otherwise Cholesky.
     std::vector<int> tabsup;                             // tableau indices of the support, when the tableau path applies
-    bool use_tab = c->tab_valid && free_intercept == !c->faithful;
+    bool use_tab = c->tab_valid && free_intercept == !c->faithful && !c->knobs.no_tab_refine;
     c->tab_valid = false;                                // one use: the next node solve overwrites the buffers
     if (use_tab) {
         std::vector<int> inv_perm((size_t)M + 1, -1);
@@ -495,6 +495,7 @@ partls_status partls_create(int device, partls_ctx **out)
     if (const char *e = getenv("PARTLS_GRAM_CR")) c->knobs.gram_cr = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_ROWS")) c->knobs.coop_rows = atoi(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
+    c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
     c->knobs.alt_trace = getenv("PARTLS_ALT_TRACE") != nullptr;
     c->knobs.print_stamps = getenv("PARTLS_PRINT_STAMPS") != nullptr;

@@ -52,6 +52,7 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    bool no_tab_refine = false;  // PARTLS_NO_TAB_REFINE: refinement by host Cholesky even when the node solve left its tableau (A/B tests)
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)

@@ -189,3 +189,43 @@ def test_strided_inputs_through_the_c_abi(partls):
             assert abs(t.value - ref_model.t) < 1e-10
     finally:
         lib.partls_destroy(h)
+
+
+def test_refinement_by_tableau_inverse_equals_refinement_by_cholesky(partls, oracle):
+    """The winner's data-space refinement solves its correction equations with the inverse the node solve left in its final tableau
+    (register kernel); PARTLS_NO_TAB_REFINE (read at context creation) forces the older host Cholesky of G_BB.  Both must land on the
+    same model — on a well-conditioned problem and on one with cond(X) ~ 1e4, where the un-refined Gram solution is only good to 1e-8
+    — in both intercept modes, and agree with the dense oracle."""
+    import os
+    rng = np.random.default_rng(4242)
+    for cond in (1.0, 1e4):
+        N, D, K = 400, 24, 4
+        U, _ = np.linalg.qr(rng.standard_normal((N, D)))
+        V, _ = np.linalg.qr(rng.standard_normal((D, D)))
+        X = (U * np.geomspace(1.0, 1.0 / cond, D)) @ V.T * np.sqrt(N)
+        P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+        y = X @ (rng.random(D) * np.array([1.0, -2.0, 0.5, 3.0])[np.arange(D) % K]) + 1.5 + 0.05 * rng.standard_normal(N)
+        ref = oracle.fit_opt(X, y, P)
+        got = {}
+        for mode in ("tab", "chol"):
+            if mode == "chol":
+                os.environ["PARTLS_NO_TAB_REFINE"] = "1"
+            try:
+                ctx = partls.Context()
+            finally:
+                os.environ.pop("PARTLS_NO_TAB_REFINE", None)
+            for flags in (0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT):
+                ctx.opt_prepare(X, y, P, 0.0, flags)
+                bo, bp, _, unconv = ctx.opt_sweep(0, -1)
+                assert unconv == 0
+                got[(mode, flags)] = ctx.opt_finish(bp)
+            ctx.close()
+        for flags in (0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT):
+            a1, b1, t1, o1, i1 = got[("tab", flags)]
+            a2, b2, t2, o2, i2 = got[("chol", flags)]
+            assert i1 == i2
+            assert abs(o1 - o2) <= 1e-12 * max(1.0, o2)
+            np.testing.assert_allclose(a1, a2, atol=1e-9)
+            np.testing.assert_allclose(b1, b2, atol=1e-9 * max(1.0, np.abs(b2).max()))
+            assert abs(t1 - t2) <= 1e-9 * max(1.0, abs(t2))
+            assert abs(o1 - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
