@@ -630,8 +630,10 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
         double st[32] = {0};
         if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
             fprintf(stderr, "[partls stamps] scan: pre %.0f barrier %.0f post %.0f | gather: work %.0f barrier %.0f | panel: work %.0f barrier %.0f | "
-                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu || gather split: block setup %.0f chain %.0f rhs/myj %.0f\n",
-                    st[9], st[10], st[0], st[12] + st[13] + st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1], st[12], st[13], st[8]);
+                            "update %.0f | scatter %.0f | chain-load %.0f/%.0f | pivots %llu || gather split: block setup %.0f chain %.0f rhs/myj %.0f"
+                            " || workgroup 0: %.0f blocks, %.0f scans, %.0f pivots\n",
+                    st[9], st[10], st[0], st[12] + st[13] + st[8], st[1], st[11], st[2], st[3], st[4], st[5], st[6], cnt[1], st[12], st[13], st[8],
+                    st[24], st[25], st[26]);
     }
     double bobj = INFINITY;
     int64_t bpat = -1;

@@ -86,7 +86,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane:
 #ifndef PARTLS_STAMP_TID
 #define PARTLS_STAMP_TID 0
 #endif
-#define STAMP_FLUSH do { if (tid == PARTLS_STAMP_TID && blockIdx.x == 0 && p.scratch) for (int _i = 0; _i < 24; ++_i) p.scratch[_i] = (double)st_acc[_i]; } while (0)
+#define STAMP_FLUSH do { if (tid == PARTLS_STAMP_TID && blockIdx.x == 0 && p.scratch) { for (int _i = 0; _i < 24; ++_i) p.scratch[_i] = (double)st_acc[_i]; \
+                                p.scratch[24] = (double)bc; p.scratch[25] = (double)sc; p.scratch[26] = (double)npiv; } } while (0)   /* + blocks, scans, pivots of workgroup 0 */
 #else
 #define STAMP_DECL
 #define STAMP(ph) do { } while (0)
