@@ -216,20 +216,24 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     p.node_code = c->nodeCode.as<int8_t>();
     p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
     // the caller will refine this one solution: have the register kernel leave its final tableau (refine_solution's solver)
-    const bool dump = want_tab && cnt == 1 && c->use_reg;
-    const size_t tabd = dump ? sweep_reg_t0_doubles(c->T) : 0;
+    // (the cooperative kernel's tableau already lives in global memory: the current image and its basis flags are copied below)
+    const bool dump_reg = want_tab && cnt == 1 && c->use_reg, dump_coop = want_tab && coop;
+    const bool dump = dump_reg || dump_coop;
+    const size_t tabd = dump_reg ? sweep_reg_t0_doubles(c->T) : (dump_coop ? (size_t)ld * ld : 0);
     if (dump) {
-        PARTLS_HIP_CHECK(c->nodeTab.ensure(tabd * sizeof(double)));
-        PARTLS_HIP_CHECK(c->nodeBasic.ensure((size_t)16 * c->T));
+        if (dump_reg) {
+            PARTLS_HIP_CHECK(c->nodeTab.ensure(tabd * sizeof(double)));
+            PARTLS_HIP_CHECK(c->nodeBasic.ensure((size_t)16 * c->T));
+        }
         if (c->hTabDoubles < tabd) {                                   // pinned: the 0.3 MB copy then costs ~20 us instead of ~150
             if (c->hTab) (void)hipHostFree(c->hTab);
             if (c->hBasic) (void)hipHostFree(c->hBasic);
             c->hTab = nullptr; c->hBasic = nullptr; c->hTabDoubles = 0;
             PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hTab, tabd * sizeof(double), hipHostMallocDefault));
-            PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hBasic, (size_t)16 * 32 /* >= 16 x MAXT of sweep_blk.hip */, hipHostMallocDefault));
+            PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->hBasic, 1024 + 16 /* >= 16 x MAXT of sweep_blk.hip, >= n + 1 <= 1024 flags of the cooperative kernel */, hipHostMallocDefault));
             c->hTabDoubles = tabd;
         }
-        p.node_tab = c->nodeTab.as<double>(); p.node_basic = c->nodeBasic.as<int8_t>();
+        if (dump_reg) { p.node_tab = c->nodeTab.as<double>(); p.node_basic = c->nodeBasic.as<int8_t>(); }
     }
     if (coop) {
         // one large problem: many workgroups cooperate on a single global-memory tableau (sweep_coop.hip)
@@ -251,14 +255,22 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->nodeSol.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(obj2.data(), c->nodeObj.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
-    if (dump) {
+    if (dump_reg) {
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->nodeTab.p, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hBasic, c->nodeBasic.p, (size_t)16 * c->T, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (dump_coop) {                                               // flags [n] + index of the current tableau image, then that image
+        const char *flagbuf = static_cast<const char *>(c->scratch.p) + (size_t)2 * ld * ld * sizeof(double);
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->hBasic, flagbuf, (size_t)n + 1, hipMemcpyDeviceToHost, c->stream));
+        PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        const size_t img = (size_t)(c->hBasic[n] & 1) * ld * ld;
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->scratch.as<double>() + img, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (unconv) *unconv = counters[0];
     c->last_pivots = counters[1]; c->last_vetoes = counters[2]; c->last_blocks = counters[3];
     c->tab_valid = dump && counters[0] == 0;
+    c->tab_full = dump_coop;                                       // layout of hTab: full (n+1)^2 matrix, or the register kernel's tiles
     return PARTLS_OK;
 }
 
@@ -328,7 +340,10 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         }
         if ((int)tabsup.size() != nb) use_tab = false;
     }
-    auto tab_entry = [&](int i, int j) -> double {       // T(i, j) of the dumped tableau (tile-cyclic layout of T0, upper tiles stored)
+    const bool tab_full = c->tab_full;
+    const int tld = c->n + 1;
+    auto tab_entry = [&](int i, int j) -> double {       // T(i, j) of the dumped tableau: full matrix, or the tile-cyclic layout of T0 (upper tiles stored)
+        if (tab_full) return c->hTab[(size_t)i * tld + j];
         int ti = i >> 4, tj = j >> 4, a = i & 15, b = j & 15;
         if (ti > tj) { std::swap(ti, tj); std::swap(a, b); }
         return c->hTab[((size_t)(tj * (tj + 1) / 2 + ti)) * 256 + a + 16 * b];

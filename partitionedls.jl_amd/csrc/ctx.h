@@ -94,7 +94,7 @@ struct partls_ctx {
     double *hTab = nullptr;
     int8_t *hBasic = nullptr;
     size_t hTabDoubles = 0;
-    bool tab_valid = false;
+    bool tab_valid = false, tab_full = false;
 };
 
 namespace partls {

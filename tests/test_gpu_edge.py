@@ -193,18 +193,18 @@ def test_strided_inputs_through_the_c_abi(partls):
 
 def test_refinement_by_tableau_inverse_equals_refinement_by_cholesky(partls, oracle):
     """The winner's data-space refinement solves its correction equations with the inverse the node solve left in its final tableau
-    (register kernel); PARTLS_NO_TAB_REFINE (read at context creation) forces the older host Cholesky of G_BB.  Both must land on the
+    (register kernel, or the cooperative kernel's global image beyond n = 320); PARTLS_NO_TAB_REFINE (read at context creation) forces
+    the older host Cholesky of G_BB.  Both must land on the
     same model — on a well-conditioned problem and on one with cond(X) ~ 1e4, where the un-refined Gram solution is only good to 1e-8
     — in both intercept modes, and agree with the dense oracle."""
     import os
     rng = np.random.default_rng(4242)
-    for cond in (1.0, 1e4):
-        N, D, K = 400, 24, 4
+    for cond, N, D, K in ((1.0, 400, 24, 4), (1e4, 400, 24, 4), (1e3, 700, 330, 3)):   # the last: n > 320, cooperative kernel's tableau
         U, _ = np.linalg.qr(rng.standard_normal((N, D)))
         V, _ = np.linalg.qr(rng.standard_normal((D, D)))
         X = (U * np.geomspace(1.0, 1.0 / cond, D)) @ V.T * np.sqrt(N)
         P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
-        y = X @ (rng.random(D) * np.array([1.0, -2.0, 0.5, 3.0])[np.arange(D) % K]) + 1.5 + 0.05 * rng.standard_normal(N)
+        y = X @ (rng.random(D) * np.array([1.0, -2.0, 0.5, 3.0])[np.arange(D) % K]) + 1.5 + 0.05 * rng.standard_normal(N)   # (K <= 4)
         ref = oracle.fit_opt(X, y, P)
         got = {}
         for mode in ("tab", "chol"):
