@@ -350,7 +350,9 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     };
     PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
     PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
-    PARTLS_HIP_CHECK(c->gD.ensure((size_t)(M + 1) * sizeof(double)));
+    const int xr = xtr_slices(N);
+    PARTLS_HIP_CHECK(c->gD.ensure((size_t)xr * (M + 1) * sizeof(double)));
+    std::vector<double> gpart((size_t)xr * (M + 1));
     std::vector<double> g((size_t)M + 1), d((size_t)p);
     std::vector<double> Lc((size_t)p * p, 0.0);
     // row-oriented Cholesky of the regularised Gram on the support (host copy); the inner products carry four independent
@@ -383,8 +385,13 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, c->yhatD.as<double>(), c->gD.as<double>(), c->stream));
         bool spd = true;
         if (it == 0 && !use_tab) spd = factorise();          // overlaps with the kernels just queued (the copy below waits for them)
-        PARTLS_HIP_CHECK(hipMemcpyAsync(g.data(), c->gD.p, (size_t)(M + 1) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(gpart.data(), c->gD.p, gpart.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (int64_t m = 0; m <= M; ++m) {
+            double sg = 0.0;
+            for (int r = 0; r < xr; ++r) sg += gpart[(size_t)r * (M + 1) + m];
+            g[(size_t)m] = sg;
+        }
         if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
         if (c->eta != 0.0) {                                 // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
             for (int64_t k = 0; k <= c->K; ++k) {
@@ -422,6 +429,7 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
                 w[(size_t)m] += dl; dn += dl * dl; wn += w[(size_t)m] * w[(size_t)m];
             }
             if (elim) { dI /= gII; w[(size_t)M] += dI; dn += dI * dI; wn += w[(size_t)M] * w[(size_t)M]; }
+            if (c->knobs.finish_trace) fprintf(stderr, "[refine] step %d: |delta|/|w| = %.3e\n", it, std::sqrt(dn / (wn > 0 ? wn : 1)));
             if (dn <= 1e-18 * wn) break;
             continue;
         }

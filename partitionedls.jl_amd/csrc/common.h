@@ -89,7 +89,9 @@ hipError_t launch_alt_beta_system(const double *G, int ldg, int M, double eta, c
 hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *w, double t,
                            double *partial, int nblocks, double *yhat, hipStream_t s);
 // g[0..M] = Xo' (y - yhat): the gradient pass of the data-space refinement
-hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *g,
+// gpart: xtr_slices(N) x (M + 1) partial sums; g[m] = sum over the slices in order
+int        xtr_slices(int64_t N);
+hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *gpart,
                       hipStream_t s);
 hipError_t launch_synth(uint64_t seed, int64_t N, int64_t D, const double *wstar_dev, double *X, double *y, hipStream_t s);
 

@@ -217,38 +217,57 @@ hipError_t launch_residual(const double *X, int64_t N, int64_t M, int64_t ldX, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// g = Xo' (y - yhat) for iterative refinement of one solution in data space (corrected semi-normal equations):
-// one workgroup per column (the last one is the ones column), coalesced along the column, fixed-order block reduction.
+// g = Xo' (y - yhat) for iterative refinement of one solution in data space (corrected semi-normal equations).
+// Grid (column, row slice): workgroup (m, r) reduces rows [r0, r1) of column m (the last column is the ones column) with four
+// loads of X in flight per thread, coalesced along the column, fixed-order block reduction; the XTR_R partial sums of a column are
+// added in slice order by the caller (reproducible).  One workgroup per whole column (round 1) left each CU with a handful of loads
+// in flight: 100 us for 205 MB at C3.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xtr_kernel(const double *__restrict__ X, int64_t N, int64_t M, int64_t ldX,
                                                   const double *__restrict__ y, const double *__restrict__ yhat,
-                                                  double *__restrict__ g)
+                                                  double *__restrict__ gpart, int R)
 {
     const int64_t m = blockIdx.x;
-    double a0 = 0.0, a1 = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += 512) {
-        const double x0 = (m < M) ? X[i + m * ldX] : 1.0;
-        a0 = fma(x0, y[i] - yhat[i], a0);
-        const int64_t i2 = i + 256;
-        if (i2 < N) {
-            const double x1 = (m < M) ? X[i2 + m * ldX] : 1.0;
-            a1 = fma(x1, y[i2] - yhat[i2], a1);
+    const int r = blockIdx.y;
+    const int64_t rows = (N + R - 1) / R, r0 = (int64_t)r * rows, r1 = (r0 + rows < N) ? r0 + rows : N;
+    const double *col = X + m * ldX;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int64_t i = r0 + threadIdx.x;
+    if (m < M) {
+        for (; i + 768 < r1; i += 1024) {
+            double x[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { x[u] = col[i + 256 * u]; d[u] = y[i + 256 * u] - yhat[i + 256 * u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = fma(x[u], d[u], acc[u]);
         }
+        for (; i < r1; i += 256) acc[0] = fma(col[i], y[i] - yhat[i], acc[0]);
+    } else {
+        for (; i < r1; i += 256) acc[0] += y[i] - yhat[i];
     }
     __shared__ double red[256];
-    red[threadIdx.x] = a0 + a1;
+    red[threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) g[m] = red[0];
+    if (threadIdx.x == 0) gpart[(size_t)r * (M + 1) + m] = red[0];
 }
 
-hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *g,
+int xtr_slices(int64_t N)
+{
+    int R = (int)((N + 16383) / 16384);
+    if (R < 1) R = 1;
+    if (R > 16) R = 16;
+    return R;
+}
+
+hipError_t launch_xtr(const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, const double *yhat, double *gpart,
                       hipStream_t s)
 {
-    hipLaunchKernelGGL(xtr_kernel, dim3((unsigned)(M + 1)), dim3(256), 0, s, X, N, M, ldX, y, yhat, g);
+    const int R = xtr_slices(N);
+    hipLaunchKernelGGL(xtr_kernel, dim3((unsigned)(M + 1), (unsigned)R), dim3(256), 0, s, X, N, M, ldX, y, yhat, gpart, R);
     return hipGetLastError();
 }
 
