@@ -129,45 +129,73 @@ hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64
 // ---------------------------------------------------------------------------------------------------------------------
 // beta-step system of fit(Alt) in Gram form (Alt.jl:109-110):  H = A' Greg A,  g = A' c  with  A = Po o alpha  ((M+1) x K').
 // Two tiny kernels with fixed summation orders (run-to-run reproducible, no atomics):
-//   1. GA[m][k2] = sum_{m2 in group k2} Greg[m][m2] alpha_m2          (one wave per row m, lane k2 walks the row)
+//   1. GA[m][k2] = sum_{m2 in group k2} Greg[m][m2] alpha_m2          (one workgroup per row m, lane = k2)
 //   2. H[k][k2]  = sum_{m in group k} alpha_m GA[m][k2],   g[k] = sum_{m in group k} alpha_m Greg[m][y]
 // On the host this was an M^2 loop per Alt iteration (0.3 ms at D = 512, a quarter of an iteration).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void alt_ga_kernel(const double *__restrict__ G, int ldg, int M, double eta,
-                                                    const uint64_t *__restrict__ mask_aug, const double *__restrict__ a, int Kp,
-                                                    double *__restrict__ GA)
+// both kernels: lane = group index (K' <= 64), the 16 waves of the workgroup take the variables m = wave, wave + 16, ...; the 16
+// partial sums of a lane are added in wave order by wave 0 (fixed order).  (One thread walking all M + 1 variables: 75 us per
+// kernel at D = 512 — latency of 513 dependent steps.)
+static constexpr int ALT_WAVES = 16;
+
+__global__ __launch_bounds__(64 * ALT_WAVES) void alt_ga_kernel(const double *__restrict__ G, int ldg, int M, double eta,
+                                                               const uint64_t *__restrict__ mask_aug, const double *__restrict__ a, int Kp,
+                                                               double *__restrict__ GA)
 {
-    const int m = blockIdx.x, k2 = threadIdx.x, Mp = M + 1;
-    if (k2 >= Kp) return;
+    __shared__ double part[ALT_WAVES][64];
+    const int m = blockIdx.x, k2 = threadIdx.x & 63, wave = threadIdx.x >> 6, Mp = M + 1;
     double s = 0.0;
-    for (int m2 = 0; m2 < Mp; ++m2)
-        if ((mask_aug[m2] >> k2) & 1ULL) s = fma(reg_entry(G, ldg, M, eta, mask_aug, m, m2), a[m2], s);
-    GA[(size_t)m * Kp + k2] = s;
+    if (k2 < Kp)
+        for (int m2 = wave; m2 < Mp; m2 += ALT_WAVES)
+            if ((mask_aug[m2] >> k2) & 1ULL) s = fma(reg_entry(G, ldg, M, eta, mask_aug, m, m2), a[m2], s);
+    part[wave][k2] = s;
+    __syncthreads();
+    if (wave == 0 && k2 < Kp) {
+        double t = 0.0;
+        for (int w = 0; w < ALT_WAVES; ++w) t += part[w][k2];
+        GA[(size_t)m * Kp + k2] = t;
+    }
 }
 
-__global__ void alt_h_kernel(const double *__restrict__ G, int ldg, int M, double eta, const uint64_t *__restrict__ mask_aug,
-                             const double *__restrict__ a, int Kp, const double *__restrict__ GA, double *__restrict__ Hg)
+__global__ __launch_bounds__(64 * ALT_WAVES) void alt_h_kernel(const double *__restrict__ G, int ldg, int M, double eta,
+                                                              const uint64_t *__restrict__ mask_aug, const double *__restrict__ a, int Kp,
+                                                              const double *__restrict__ GA, double *__restrict__ Hg)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x, Mp = M + 1;
-    if (idx >= Kp * (Kp + 1)) return;
-    const int k = idx / (Kp + 1), k2 = idx % (Kp + 1);             // column Kp of row k holds g[k]
-    double s = 0.0;
-    for (int m = 0; m < Mp; ++m) {
+    __shared__ double part[ALT_WAVES][65];
+    const int k = blockIdx.x, k2 = threadIdx.x & 63, wave = threadIdx.x >> 6, Mp = M + 1;     // column Kp of row k holds g[k] (Kp <= 64: lane Kp <= 64 ... handled by lane 63 when Kp == 64)
+    // lanes 0..Kp-1: H[k][k2]; the g column is computed by lane Kp when Kp < 64, else by a second pass of lane 0
+    auto term = [&](int m, int col) { return col < Kp ? GA[(size_t)m * Kp + col] : reg_entry(G, ldg, M, eta, mask_aug, m, M + 1); };
+    double s = 0.0, sg = 0.0;
+    for (int m = wave; m < Mp; m += ALT_WAVES) {
         if (!((mask_aug[m] >> k) & 1ULL)) continue;
-        const double v = (k2 < Kp) ? GA[(size_t)m * Kp + k2] : reg_entry(G, ldg, M, eta, mask_aug, m, M + 1);
-        s = fma(a[m], v, s);
+        const double am = a[m];
+        if (k2 < Kp) s = fma(am, term(m, k2), s);
+        if (k2 == 0) sg = fma(am, term(m, Kp), sg);
     }
-    Hg[idx] = s;
+    part[wave][k2] = s;
+    if (k2 == 0) part[wave][64] = sg;
+    __syncthreads();
+    if (wave == 0) {
+        if (k2 < Kp) {
+            double t = 0.0;
+            for (int w = 0; w < ALT_WAVES; ++w) t += part[w][k2];
+            Hg[(size_t)k * (Kp + 1) + k2] = t;
+        }
+        if (k2 == 0) {
+            double t = 0.0;
+            for (int w = 0; w < ALT_WAVES; ++w) t += part[w][64];
+            Hg[(size_t)k * (Kp + 1) + Kp] = t;
+        }
+    }
 }
 
 hipError_t launch_alt_beta_system(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, const double *a, int Kp,
                                   double *GA, double *Hg, hipStream_t s)
 {
-    hipLaunchKernelGGL(alt_ga_kernel, dim3(M + 1), dim3(64), 0, s, G, ldg, M, eta, mask_aug, a, Kp, GA);
+    hipLaunchKernelGGL(alt_ga_kernel, dim3(M + 1), dim3(64 * ALT_WAVES), 0, s, G, ldg, M, eta, mask_aug, a, Kp, GA);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int tot = Kp * (Kp + 1);
-    hipLaunchKernelGGL(alt_h_kernel, dim3((tot + 63) / 64), dim3(64), 0, s, G, ldg, M, eta, mask_aug, a, Kp, GA, Hg);
+    hipLaunchKernelGGL(alt_h_kernel, dim3(Kp), dim3(64 * ALT_WAVES), 0, s, G, ldg, M, eta, mask_aug, a, Kp, GA, Hg);
     return hipGetLastError();
 }
 
