@@ -185,11 +185,11 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     if (codes.size() != cnt * (size_t)n) { set_error("solve_nodes: code array has the wrong size"); return PARTLS_ERR_BAD_ARG; }
     const int grid = (int)std::min<size_t>(cnt, c->use_reg ? 2048 : 512);
     PARTLS_HIP_CHECK(c->nodeCode.ensure(cnt * (size_t)n));
-    PARTLS_HIP_CHECK(c->nodeSol.ensure(cnt * (size_t)n * sizeof(double)));
-    PARTLS_HIP_CHECK(c->nodeObj.ensure(cnt * sizeof(double)));
+    // one output block on the device, one copy back: [counters (4 x 8 B) | objective^2 (cnt) | solutions (cnt x n)]
+    const size_t out_words = 4 + cnt + cnt * (size_t)n;
+    PARTLS_HIP_CHECK(c->nodeSol.ensure(out_words * sizeof(double)));
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
-    PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
     const bool coop = !c->use_reg && cnt == 1 && !c->knobs.no_coop;
     if (coop) {
         const size_t need = ((size_t)2 * ld * ld + (size_t)n / 8 + 2) * sizeof(double);  // two tableau images + basis flags + current image
@@ -200,7 +200,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
         else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
     }
-    PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->nodeSol.p, 0, 4 * sizeof(unsigned long long), c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeCode.p, codes.data(), cnt * (size_t)n, hipMemcpyHostToDevice, c->stream));
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
@@ -210,11 +210,11 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
     p.all_opt = nullptr;
     p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
-    p.n_unconverged = c->counters.as<unsigned long long>();
-    p.n_pivots = c->counters.as<unsigned long long>() + 1;
-    p.n_vetoes = c->counters.as<unsigned long long>() + 2;
+    p.n_unconverged = c->nodeSol.as<unsigned long long>();
+    p.n_pivots = c->nodeSol.as<unsigned long long>() + 1;
+    p.n_vetoes = c->nodeSol.as<unsigned long long>() + 2;
     p.node_code = c->nodeCode.as<int8_t>();
-    p.node_sol = c->nodeSol.as<double>(); p.node_obj2 = c->nodeObj.as<double>(); p.node_ld = n;
+    p.node_obj2 = c->nodeSol.as<double>() + 4; p.node_sol = c->nodeSol.as<double>() + 4 + cnt; p.node_ld = n;
     // the caller will refine this one solution: have the register kernel leave its final tableau (refine_solution's solver)
     // (the cooperative kernel's tableau already lives in global memory: the current image and its basis flags are copied below)
     const bool dump_reg = want_tab && cnt == 1 && c->use_reg, dump_coop = want_tab && coop;
@@ -252,9 +252,8 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
     }
     unsigned long long counters[4] = {0, 0, 0, 0};                 // unconverged, pivots, vetoes, (cooperative kernel) blocks
-    PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->nodeSol.p, cnt * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(obj2.data(), c->nodeObj.p, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(counters, c->counters.p, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> outw(out_words);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(outw.data(), c->nodeSol.p, out_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (dump_reg) {
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->nodeTab.p, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hBasic, c->nodeBasic.p, (size_t)16 * c->T, hipMemcpyDeviceToHost, c->stream));
@@ -267,6 +266,9 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->scratch.as<double>() + img, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::memcpy(counters, outw.data(), sizeof(counters));
+    std::copy(outw.begin() + 4, outw.begin() + 4 + (ptrdiff_t)cnt, obj2.begin());
+    std::copy(outw.begin() + 4 + (ptrdiff_t)cnt, outw.end(), sols.begin());
     if (unconv) *unconv = counters[0];
     c->last_pivots = counters[1]; c->last_vetoes = counters[2]; c->last_blocks = counters[3];
     c->tab_valid = dump && counters[0] == 0;

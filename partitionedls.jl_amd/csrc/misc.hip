@@ -144,10 +144,25 @@ __global__ __launch_bounds__(64 * ALT_WAVES) void alt_ga_kernel(const double *__
 {
     __shared__ double part[ALT_WAVES][64];
     const int m = blockIdx.x, k2 = threadIdx.x & 63, wave = threadIdx.x >> 6, Mp = M + 1;
+    // branch-free and unrolled: the loads of a step are wave-uniform (row m of G, alpha and the mask of variable m2), eight steps
+    // are in flight together; a lane adds the product when variable m2 belongs to ITS group
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
     double s = 0.0;
-    if (k2 < Kp)
-        for (int m2 = wave; m2 < Mp; m2 += ALT_WAVES)
-            if ((mask_aug[m2] >> k2) & 1ULL) s = fma(reg_entry(G, ldg, M, eta, mask_aug, m, m2), a[m2], s);
+    int m2 = wu;
+    for (; m2 + 7 * ALT_WAVES < Mp; m2 += 8 * ALT_WAVES) {
+        double v[8];
+        uint64_t mk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int mm = m2 + u * ALT_WAVES;
+            mk[u] = mask_aug[mm];
+            v[u] = reg_entry(G, ldg, M, eta, mask_aug, m, mm) * a[mm];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += ((mk[u] >> k2) & 1ULL) ? v[u] : 0.0;
+    }
+    for (; m2 < Mp; m2 += ALT_WAVES) s += ((mask_aug[m2] >> k2) & 1ULL) ? reg_entry(G, ldg, M, eta, mask_aug, m, m2) * a[m2] : 0.0;
+    if (k2 >= Kp) s = 0.0;
     part[wave][k2] = s;
     __syncthreads();
     if (wave == 0 && k2 < Kp) {
