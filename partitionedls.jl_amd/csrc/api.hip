@@ -629,10 +629,10 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     int grid = (int)std::min<int64_t>(nchains, c->knobs.grid > 0 ? c->knobs.grid : (c->use_reg ? 4096 : 1024));
     if (grid < 1) grid = 1;
 
-    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * std::max(grid, 4096)));
-    PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * std::max(grid, 4096)));
-    PARTLS_HIP_CHECK(c->counters.ensure(4 * sizeof(unsigned long long)));
-    PARTLS_HIP_CHECK(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), c->stream));
+    // one output block on the device, one copy back: [counters (4 x 8 B) | best objective (grid) | best pattern (grid)]
+    const size_t sweep_words = 4 + 2 * (size_t)grid;
+    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 2 * (size_t)std::max(grid, 4096))));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->bestObj.p, 0, 4 * sizeof(unsigned long long), c->stream));
     if (all_opt) PARTLS_HIP_CHECK(c->allOpt.ensure((size_t)npat * sizeof(double)));
     if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
     else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
@@ -644,10 +644,10 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.g_begin = g_begin; p.g_end = g_end; p.chain_len = chain_len;
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
     p.all_opt = all_opt ? c->allOpt.as<double>() : nullptr;
-    p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
-    p.n_unconverged = c->counters.as<unsigned long long>();
-    p.n_pivots = c->counters.as<unsigned long long>() + 1;
-    p.n_vetoes = c->counters.as<unsigned long long>() + 2;
+    p.best_obj = c->bestObj.as<double>() + 4; p.best_pat = reinterpret_cast<int64_t *>(c->bestObj.as<double>() + 4 + grid);
+    p.n_unconverged = c->bestObj.as<unsigned long long>();
+    p.n_pivots = c->bestObj.as<unsigned long long>() + 1;
+    p.n_vetoes = c->bestObj.as<unsigned long long>() + 2;
 
     t_begin(c, PARTLS_T_SWEEP);
     PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
@@ -656,15 +656,17 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     std::vector<double> bo((size_t)grid);
     std::vector<int64_t> bp((size_t)grid);
     unsigned long long cnt[3] = {0, 0, 0};
-    PARTLS_HIP_CHECK(hipMemcpyAsync(bo.data(), c->bestObj.p, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(bp.data(), c->bestPat.p, (size_t)grid * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(cnt, c->counters.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> sweep_out(sweep_words);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(sweep_out.data(), c->bestObj.p, sweep_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (all_opt) {
         // only the entries of this shard are defined; the caller merges shards (entries are indexed by pattern)
         PARTLS_HIP_CHECK(hipMemcpyAsync(all_opt, c->allOpt.p, (size_t)npat * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
+    std::memcpy(cnt, sweep_out.data(), sizeof(cnt));
+    std::memcpy(bo.data(), sweep_out.data() + 4, (size_t)grid * sizeof(double));
+    std::memcpy(bp.data(), sweep_out.data() + 4 + grid, (size_t)grid * sizeof(int64_t));
     c->last_pivots = cnt[1];
     c->last_vetoes = cnt[2];
     if (c->knobs.print_stamps) {                         // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
