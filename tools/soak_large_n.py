@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the global-memory kernels (n > 320: sweep_generic enumeration, sweep_coop single solves) against the oracle:
 fit(Alt) from the same start and fit(Opt) on problems with 321..420 features, some with dependent columns.
-usage: python tools/soak_large_n.py [problems] [seed]"""
+usage: python tools/soak_large_n.py [problems] [seed] [Dmin Dmax]   (default 321..420; 257..320 exercises the register kernel at T = 17..20)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, partls_amd
@@ -9,9 +9,11 @@ from oracle import oracle as O
 pls = partls_amd.package()
 nprob = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
+dlo = int(sys.argv[3]) if len(sys.argv) > 4 else 321
+dhi = int(sys.argv[4]) if len(sys.argv) > 4 else 420
 bad = 0
 for it in range(nprob):
-    D = int(rng.integers(321, 421)); K = int(rng.integers(2, 5)); N = int(D * rng.uniform(1.3, 2.5)) + 7
+    D = int(rng.integers(dlo, dhi + 1)); K = int(rng.integers(2, 5)); N = int(D * rng.uniform(1.3, 2.5)) + 7
     X = rng.standard_normal((N, D))
     kind = rng.random()
     if kind < 0.3:
