@@ -29,7 +29,7 @@ typedef enum {
     PARTLS_OK = 0,
     PARTLS_ERR_BAD_ARG = 1,        /* null pointer, negative size, ld < rows, K too large ...            */
     PARTLS_ERR_BAD_PARTITION = 2,  /* P has an entry outside {0,1} (PartitionedLS.jl:292 validity clause) */
-    PARTLS_ERR_NONFINITE = 3,      /* NaN/Inf in X or y                                                   */
+    PARTLS_ERR_NONFINITE = 3,      /* NaN/Inf in X or y, or a column whose sum of squares overflows fp64    */
     PARTLS_ERR_NO_DEVICE = 4,      /* no HIP device / device index out of range                           */
     PARTLS_ERR_HIP = 5,            /* a HIP runtime call failed (message has the hipError string)         */
     PARTLS_ERR_NOT_CONVERGED = 6,  /* an active-set solve hit its pivot cap                               */
