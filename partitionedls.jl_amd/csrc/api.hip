@@ -114,17 +114,23 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     c->mask_tab.resize((size_t)c->n);
     for (int i = 0; i < c->n; ++i) c->mask_tab[(size_t)i] = c->mask_aug[(size_t)c->perm[(size_t)i]];
 
-    PARTLS_HIP_CHECK(c->maskAugD.ensure(((size_t)M + 2) * sizeof(uint64_t)));
-    PARTLS_HIP_CHECK(c->maskTabD.ensure((size_t)c->n * sizeof(uint64_t)));
-    PARTLS_HIP_CHECK(c->permD.ensure((size_t)c->n * sizeof(int)));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskAugD.p, c->mask_aug.data(), ((size_t)M + 2) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskTabD.p, c->mask_tab.data(), (size_t)c->n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->permD.p, c->perm.data(), (size_t)c->n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // one upload: [group masks of the augmented variables (M + 2) | group masks in tableau order (n) | permutation (n ints)]
+    {
+        const size_t words = (size_t)M + 2 + (size_t)c->n + ((size_t)c->n + 1) / 2;
+        c->pack.assign(words, 0);
+        std::memcpy(c->pack.data(), c->mask_aug.data(), ((size_t)M + 2) * sizeof(uint64_t));
+        std::memcpy(c->pack.data() + M + 2, c->mask_tab.data(), (size_t)c->n * sizeof(uint64_t));
+        std::memcpy(c->pack.data() + M + 2 + c->n, c->perm.data(), (size_t)c->n * sizeof(int));
+        PARTLS_HIP_CHECK(c->maskAugD.ensure(words * sizeof(uint64_t)));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskAugD.p, c->pack.data(), words * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+        c->maskTabP = c->maskAugD.as<uint64_t>() + M + 2;
+        c->permP = reinterpret_cast<int *>(c->maskAugD.as<uint64_t>() + M + 2 + c->n);
+    }
     PARTLS_HIP_CHECK(c->scale.ensure((size_t)c->n * sizeof(double)));
     PARTLS_HIP_CHECK(c->Tfull.ensure((size_t)(c->n + 1) * (c->n + 1) * sizeof(double)));
     t_begin(c, PARTLS_T_PREP);
     PARTLS_HIP_CHECK(launch_prep(c->G.as<double>(), c->ldg, (int)M, eta, c->maskAugD.as<uint64_t>(), faithful ? 0 : 1,
-                                 c->permD.as<int>(), c->scale.as<double>(), c->Tfull.as<double>(), c->n, c->stream));
+                                 c->permP, c->scale.as<double>(), c->Tfull.as<double>(), c->n, c->stream));
     c->use_reg = sweep_reg_supported(c->n) && !(flags & PARTLS_OPT_GENERIC_KERNEL);
     if (c->use_reg) {
         c->T = sweep_reg_tiles(c->n);
@@ -204,7 +210,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeCode.p, codes.data(), cnt * (size_t)n, hipMemcpyHostToDevice, c->stream));
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
-    p.mask = c->maskTabD.as<uint64_t>();
+    p.mask = c->maskTabP;
     p.scratch = c->scratch.as<double>();
     p.g_begin = 0; p.g_end = (int64_t)cnt; p.chain_len = 1;
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
@@ -564,7 +570,7 @@ void partls_destroy(partls_ctx *c)
     const bool alive = hipGetDeviceCount(&ndev) == hipSuccess && ndev > c->device && hipSetDevice(c->device) == hipSuccess;
     if (alive) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->maskTabD, &c->permD, &c->scale, &c->Tfull,
+        DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->scale, &c->Tfull,
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
                           &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
                           &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic, &c->altA, &c->altGA, &c->altHg};
@@ -639,7 +645,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
 
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
-    p.mask = c->maskTabD.as<uint64_t>();
+    p.mask = c->maskTabP;
     p.scratch = c->scratch.as<double>();
     p.g_begin = g_begin; p.g_end = g_end; p.chain_len = chain_len;
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);

@@ -76,9 +76,12 @@ struct partls_ctx {
     partls::DevBuf ownX, ownY;
     std::vector<int64_t> P;                        // M x K compact
     std::vector<uint64_t> mask_aug;                // M + 2: features, intercept (bit K), y (0)
+    std::vector<uint64_t> pack;                    // staging of the one upload of masks and permutation
+    const uint64_t *maskTabP = nullptr;            // views into maskAugD: group masks in tableau order, permutation
+    const int *permP = nullptr;
     // gram
     int ldg = 0, chunks = 0;
-    partls::DevBuf slab, G, maskAugD, maskTabD, permD, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
+    partls::DevBuf slab, G, maskAugD /* + maskTabP, permP: one upload */, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
         wdev, partial, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic, altA, altGA, altHg;
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
     std::vector<double> hScale;
