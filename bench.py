@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over the synthetic problem, inputs resident in HBM when the timed region starts.
-  C2 / C3 (fit(Opt)): Gram build (fp64 MFMA) -> tableau prep -> sign-pattern sweep over this rank's shard of the Gray-index space
+  C2 / C3 (fit(Opt)): Gram build (fp64 MFMA) -> tableau prep -> [long enumerations: bit-order calibration, ~0.4 ms, every step]
+        -> sign-pattern sweep over this rank's shard of the Gray-index space
         -> all-reduce(min objective, then min index among the minimisers) over RCCL -> winner re-solve + objective from the data.
         The 2^K' patterns of ONE problem are sharded across ranks (total work fixed => "strong" scaling); no data-path collective
         besides the two 8-byte all-reduces.  value = patterns solved by all ranks / max-over-ranks time.
@@ -100,14 +101,17 @@ def main():
         ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, flags)
         npat = ctx.num_patterns()
         g0, g1 = pls.dist.shard_range(npat, rank, world)
+        # the ranges partition the pattern space only if every rank visits it in the same order: the key of this rank's order
+        # (measured group -> Gray-bit assignment, deterministic in the data) rides in the first all-reduce and is compared there
+        okey = pls.dist.order_key(ctx.bit_order()[0]) if world > 1 else None
         bobj, bpat, _, unconv = ctx.opt_sweep(g0, g1)
-        t_gram, t_prep, t_sweep = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP)
+        t_gram, t_prep, t_sweep, t_calib = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP), ctx.timing(L.T_CALIB)
         pivots, vetoes = ctx.pivots(), ctx.vetoes()
         # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
-        _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=red_dev)
+        _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=red_dev, order_key=okey)
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         return dict(npat=npat, local=g1 - g0, opt=opt, best_index=bi, unconv=unconv, t_gram=t_gram, t_prep=t_prep,
-                    t_sweep=t_sweep, t_finish=ctx.timing(L.T_FINISH), pivots=pivots, vetoes=vetoes)
+                    t_sweep=t_sweep, t_calib=t_calib, t_finish=ctx.timing(L.T_FINISH), pivots=pivots, vetoes=vetoes)
 
     def bnb_pass(cap=None):
         ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
@@ -188,7 +192,8 @@ def main():
         out["roofline_fp64"] = {"bound": "fp64 vector FMA", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": fp64_tflops / FP64_PEAK_TFLOPS, "pivots_per_launch": res["pivots"],
                                 "note": "the kernel's real bound: fp64 FMA issue of the rank-1 tableau updates"}
-        out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
+        out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "bit_order_calibration": avg("t_calib"),
+                             "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
         out["gram"] = {"tflops_useful": gram_flops / (avg("t_gram") * 1e-3) / 1e12, "frac_of_fp64_mfma_peak":
                        gram_flops / (avg("t_gram") * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
         out["result"] = {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"], "loo_vetoes": res["vetoes"]}

@@ -68,7 +68,12 @@ partls_status partls_fit_opt(partls_ctx *ctx, const double *X, int64_t N, int64_
  *           x_on_device != 0: X and y are DEVICE pointers (hipMalloc / torch) and stay owned by the caller.
  * sweep:    enumerates Gray indices [g_begin, g_end) of the 2^K' pattern space (K' = K+1 faithful, K free intercept);
  *           g_end = -1 means "to the end".  Returns the shard's lexicographic minimum (objective, pattern index) —
- *           the pair a rank feeds into the all-reduce(min).  all_opt as above (indexed by pattern, not by Gray index).
+ *           the pair a rank feeds into the all-reduce(min).  all_opt as above (indexed by pattern, not by Gray index;
+ *           entries of patterns outside [g_begin, g_end) are set to NaN).
+ *           Gray indices are positions in the context's own visiting order: which group sits on which Gray bit is chosen
+ *           per prepared problem (partls_opt_bit_order; measured on the first sweep of long enumerations, deterministic in
+ *           the data, so ranks that prepared the same problem agree).  Any disjoint ranges covering [0, 2^K') visit every
+ *           pattern exactly once; every pattern index that crosses this boundary is the reference's (group k = bit k).
  * finish:   solves the given pattern once more on its own, computes opt from the data, normalises (cleanupResult). */
 partls_status partls_opt_prepare(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                                  int x_on_device, const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags);
@@ -79,6 +84,11 @@ partls_status partls_opt_finish(partls_ctx *ctx, int64_t pattern,
 /* raw NNLS solution of one pattern b (reference indexing, K+1 bits): raw_alpha[M+1] >= 0 as nonneg_lsq returns it at
  * Opt.jl:89, and its optval (Opt.jl:90).  Needs a prepared context. */
 partls_status partls_opt_pattern(partls_ctx *ctx, int64_t pattern, double *raw_alpha, double *optval);
+/* visiting order of the sweep: gbit[k] = Gray-index bit that carries group k (K' entries; identity unless calibrated);
+ * flip_cost (optional, K' doubles): measured pivots per flip of group k, -1 when the calibration did not run (short sweeps,
+ * global-memory kernel, PARTLS_BIT_ORDER=identity).  Runs the calibration if no sweep has done so yet.  Ranks of a sharded
+ * sweep must hold the same gbit (partitionedls.jl_amd/dist.py checks it inside its first all-reduce). */
+partls_status partls_opt_bit_order(partls_ctx *ctx, int64_t *gbit, double *flip_cost);
 /* number of subproblems one full sweep solves (2^K or 2^(K+1)) for the prepared problem */
 int64_t       partls_opt_num_patterns(const partls_ctx *ctx);
 
@@ -137,7 +147,8 @@ typedef enum {
     PARTLS_T_PREP = 1,      /* η / scaling / tableau layout           */
     PARTLS_T_SWEEP = 2,     /* the sign-pattern sweep kernel          */
     PARTLS_T_FINISH = 3,    /* winner re-solve + residual from data   */
-    PARTLS_T_COUNT = 4
+    PARTLS_T_CALIB = 4,     /* bit-order calibration of the sweep (0 when it did not run) */
+    PARTLS_T_COUNT = 5
 } partls_timer;
 partls_status partls_get_timing(const partls_ctx *ctx, partls_timer which, double *ms);
 /* principal pivots executed by the last partls_opt_sweep (fp64 flop accounting: each pivot updates the whole symmetric tableau) */

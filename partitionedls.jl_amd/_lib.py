@@ -10,7 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OK, ERR_BAD_ARG, ERR_BAD_PARTITION, ERR_NONFINITE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED, ERR_STATE = range(9)
 OPT_FAITHFUL_INTERCEPT = 1
 OPT_GENERIC_KERNEL = 2
-T_GRAM, T_PREP, T_SWEEP, T_FINISH = range(4)
+T_GRAM, T_PREP, T_SWEEP, T_FINISH, T_CALIB = range(5)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -31,6 +31,7 @@ SYMBOLS = [
     ("partls_opt_finish", C.c_int, [C.c_void_p, _i64, _dp, _dp, _dp, _dp, _ip]),
     ("partls_opt_pattern", C.c_int, [C.c_void_p, _i64, _dp, _dp]),
     ("partls_opt_num_patterns", _i64, [C.c_void_p]),
+    ("partls_opt_bit_order", C.c_int, [C.c_void_p, _ip, _dp]),
     ("partls_fit_alt", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
                                  C.c_double, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     ("partls_fit_bnb", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,

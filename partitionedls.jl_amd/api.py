@@ -121,6 +121,15 @@ class Context:
     def num_patterns(self):
         return int(L.lib().partls_opt_num_patterns(self._h))
 
+    def bit_order(self):
+        """(gbit, flip_cost): gbit[k] = Gray-index bit that carries group k in this context's sweeps; flip_cost[k] = measured
+        pivots per flip of group k (-1 where the calibration did not run).  Runs the calibration if no sweep has yet."""
+        kb = self.num_patterns().bit_length() - 1
+        g = np.zeros(kb, dtype=np.int64)
+        fc = np.zeros(kb)
+        _check(L.lib().partls_opt_bit_order(self._h, _ip(g), _dp(fc)))
+        return g, fc
+
     def opt_sweep(self, g_begin=0, g_end=-1, want_all=False):
         bo = C.c_double()
         bp = C.c_int64()

@@ -78,6 +78,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
     c->prepared = false;
     c->coop_state_valid = false;
+    c->order_ready = false; c->order_identity = true; c->flip_cost.clear(); c->ms[PARTLS_T_CALIB] = 0.0;
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     st = load_partition(c, P, M, K, ldP);
     if (st != PARTLS_OK) return st;
@@ -541,6 +542,7 @@ partls_status partls_create(int device, partls_ctx **out)
     if (const char *e = getenv("PARTLS_GRAM_S")) c->knobs.gram_S = atoi(e);
     if (const char *e = getenv("PARTLS_GRAM_CR")) c->knobs.gram_cr = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_ROWS")) c->knobs.coop_rows = atoi(e);
+    if (const char *e = getenv("PARTLS_BIT_ORDER")) c->knobs.bit_order = !strcmp(e, "identity") ? 1 : (!strcmp(e, "calibrate") ? 2 : 0);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
@@ -573,7 +575,8 @@ void partls_destroy(partls_ctx *c)
         DevBuf *bufs[] = {&c->ownX, &c->ownY, &c->slab, &c->G, &c->maskAugD, &c->scale, &c->Tfull,
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
                           &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
-                          &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic, &c->altA, &c->altGA, &c->altHg};
+                          &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic, &c->altA, &c->altGA, &c->altHg,
+                          &c->nodePiv, &c->maskInt, &c->allOptRef};
         for (DevBuf *b : bufs) b->release();
         c->hG.release();
         if (c->hTab) (void)hipHostFree(c->hTab);
@@ -595,6 +598,101 @@ partls_status partls_opt_prepare(partls_ctx *c, const double *X, int64_t N, int6
 
 int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared) ? ((int64_t)1 << c->kbits) : 0; }
 
+// Which group sits on which bit of the Gray index.  Bit b flips in 2^-(b+1) of all transitions and a flip exchanges roughly the
+// variables of its group that carry signal, so the cheap groups belong on the fast bits: on C3 the reference's order (group k on
+// bit k) costs 16.9 M pivots / 74.9 ms, the measured-cost order 12.9 M / 49 ms for the same 2^20 subproblems.  The cost of a flip
+// is MEASURED on the prepared problem: `ncu` chains of nodes on the register kernel, chain c solving a pseudo-random pattern from
+// scratch and then flipping the groups of its half of the bits one after the other (each node warm-started from its predecessor,
+// exactly as in the sweep); pivots per flip are averaged per group.  Wall time = one chain = (8 + K'/2) patterns' worth, paid once
+// per prepare and only when the sweep is long enough to repay it.  Deterministic (fixed walks, no atomics in the solves), so every
+// rank of a sharded sweep derives the same order from the same data; dist.py cross-checks that before trusting the shards.
+static partls_status calibrate_bit_order(partls_ctx *c)
+{
+    const int kb = c->kbits, n = c->n;
+    c->order_ready = true;
+    c->order_identity = true;
+    c->flip_cost.clear();
+    for (int k = 0; k < 40; ++k) c->order.gbit[k] = (uint8_t)k;
+    if (!c->use_reg || kb < 2 || c->knobs.bit_order == 1) return PARTLS_OK;
+    int ncu = 256;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+    const int nseg = kb >= 8 ? 2 : 1;
+    const int seg_len = (kb + nseg - 1) / nseg, L = seg_len + 1;
+    if (c->knobs.bit_order != 2 && ((int64_t)1 << kb) < (int64_t)ncu * 12 * (8 + seg_len)) return PARTLS_OK;   // would not repay itself
+    const int chains = std::max(ncu - ncu % nseg, 2 * nseg);
+    const size_t steps = (size_t)chains * L;
+
+    PARTLS_HIP_CHECK(c->nodeCode.ensure(steps * (size_t)n));
+    PARTLS_HIP_CHECK(c->nodePiv.ensure((steps + 8) * sizeof(unsigned)));
+    PARTLS_HIP_CHECK(c->nodeSol.ensure((4 + (size_t)chains + (size_t)chains * n) * sizeof(double)));
+    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 2 * 4096)));
+    PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
+    PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
+    PARTLS_HIP_CHECK(hipMemsetAsync(c->nodePiv.p, 0, 8 * sizeof(unsigned), c->stream));          // [unconverged (8 B) | ... | pivots per step]
+    t_begin(c, PARTLS_T_CALIB);
+    PARTLS_HIP_CHECK(launch_walk_codes(c->maskTabP, n, kb, chains, L, seg_len, nseg, c->nodeCode.as<int8_t>(), c->stream));
+    SweepParams p{};
+    p.n = n; p.kbits = kb;
+    p.mask = c->maskTabP;
+    p.scratch = c->scratch.as<double>();
+    p.g_begin = 0; p.g_end = (int64_t)steps; p.chain_len = L;
+    p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
+    p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
+    p.n_unconverged = c->nodePiv.as<unsigned long long>();
+    p.node_code = c->nodeCode.as<int8_t>();
+    p.node_obj2 = c->nodeSol.as<double>() + 4; p.node_sol = c->nodeSol.as<double>() + 4 + chains; p.node_ld = n;
+    p.node_piv = c->nodePiv.as<unsigned>() + 8;
+    p.T0 = c->T0reg.as<double>();
+    PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, chains, c->stream));
+    t_end(c, PARTLS_T_CALIB);
+    std::vector<unsigned> piv(steps + 8);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(piv.data(), c->nodePiv.p, (steps + 8) * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    t_collect(c);
+    c->coop_state_valid = false;
+    c->tab_valid = false;
+    unsigned long long unconv = 0;
+    std::memcpy(&unconv, piv.data(), sizeof(unconv));
+    if (unconv) return PARTLS_OK;                            // a walk hit the pivot cap: the sample says nothing, keep the plain order
+
+    std::vector<double> cost((size_t)kb, 0.0);
+    std::vector<int> cnt((size_t)kb, 0);
+    for (int ch = 0; ch < chains; ++ch)
+        for (int i = 1; i < L; ++i) {
+            const int k = walk_flipped_bit(ch, i, kb, seg_len, nseg);
+            cost[(size_t)k] += (double)(piv[8 + (size_t)ch * L + i] - piv[8 + (size_t)ch * L + i - 1]);
+            ++cnt[(size_t)k];
+        }
+    for (int k = 0; k < kb; ++k) cost[(size_t)k] = cnt[(size_t)k] ? cost[(size_t)k] / cnt[(size_t)k] : 0.0;
+    std::vector<int> by_cost((size_t)kb);
+    std::iota(by_cost.begin(), by_cost.end(), 0);
+    std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost[(size_t)a] < cost[(size_t)b]; });
+    bool ident = true;
+    for (int b = 0; b < kb; ++b) { c->order.gbit[by_cost[(size_t)b]] = (uint8_t)b; ident = ident && by_cost[(size_t)b] == b; }
+    c->flip_cost = cost;
+    if (ident) return PARTLS_OK;
+    std::vector<uint64_t> mi((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        uint64_t m = c->mask_tab[(size_t)i], q = 0;
+        for (; m; m &= m - 1) q |= 1ULL << c->order.gbit[__builtin_ctzll(m)];
+        mi[(size_t)i] = q;
+    }
+    PARTLS_HIP_CHECK(c->maskInt.ensure((size_t)n * sizeof(uint64_t)));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->maskInt.p, mi.data(), (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));     // `mi` is pageable and goes out of scope
+    c->order_identity = false;
+    return PARTLS_OK;
+}
+
+// internal pattern (group k on bit gbit[k]) -> the reference's pattern index (group k on bit k)
+static int64_t reference_pattern(const partls_ctx *c, int64_t q)
+{
+    if (q < 0 || c->order_identity) return q;
+    uint64_t r = 0;
+    for (int k = 0; k < c->kbits; ++k) r |= (((uint64_t)q >> c->order.gbit[k]) & 1ULL) << k;
+    return (int64_t)r;
+}
+
 partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, double *best_obj, int64_t *best_pattern,
                                double *all_opt, int64_t *n_unconverged)
 {
@@ -609,6 +707,10 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
         if (best_pattern) *best_pattern = -1;
         if (n_unconverged) *n_unconverged = 0;
         return PARTLS_OK;
+    }
+    if (!c->order_ready) {
+        partls_status st = calibrate_bit_order(c);
+        if (st != PARTLS_OK) return st;
     }
     const int n = c->n, ld = n + 1;
     const int64_t total = g_end - g_begin;
@@ -639,13 +741,16 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     const size_t sweep_words = 4 + 2 * (size_t)grid;
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 2 * (size_t)std::max(grid, 4096))));
     PARTLS_HIP_CHECK(hipMemsetAsync(c->bestObj.p, 0, 4 * sizeof(unsigned long long), c->stream));
-    if (all_opt) PARTLS_HIP_CHECK(c->allOpt.ensure((size_t)npat * sizeof(double)));
+    if (all_opt) {
+        PARTLS_HIP_CHECK(c->allOpt.ensure((size_t)npat * sizeof(double)));
+        if (total < npat) PARTLS_HIP_CHECK(hipMemsetAsync(c->allOpt.p, 0xFF, (size_t)npat * sizeof(double), c->stream));   // NaN outside the shard
+    }
     if (!c->use_reg) PARTLS_HIP_CHECK(c->scratch.ensure((size_t)grid * ld * ld * sizeof(double)));
     else PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
 
     SweepParams p{};
     p.n = n; p.kbits = c->kbits;
-    p.mask = c->maskTabP;
+    p.mask = c->order_identity ? c->maskTabP : c->maskInt.as<uint64_t>();
     p.scratch = c->scratch.as<double>();
     p.g_begin = g_begin; p.g_end = g_end; p.chain_len = chain_len;
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
@@ -665,8 +770,14 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     std::vector<double> sweep_out(sweep_words);
     PARTLS_HIP_CHECK(hipMemcpyAsync(sweep_out.data(), c->bestObj.p, sweep_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (all_opt) {
-        // only the entries of this shard are defined; the caller merges shards (entries are indexed by pattern)
-        PARTLS_HIP_CHECK(hipMemcpyAsync(all_opt, c->allOpt.p, (size_t)npat * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        // only the entries of this shard are set, the others are NaN; the caller merges shards (entries are indexed by pattern)
+        const void *src = c->allOpt.p;
+        if (!c->order_identity) {                        // the kernel indexed it by the internal pattern
+            PARTLS_HIP_CHECK(c->allOptRef.ensure((size_t)npat * sizeof(double)));
+            PARTLS_HIP_CHECK(launch_pattern_gather(c->allOpt.as<double>(), npat, c->kbits, c->order, c->allOptRef.as<double>(), c->stream));
+            src = c->allOptRef.p;
+        }
+        PARTLS_HIP_CHECK(hipMemcpyAsync(all_opt, src, (size_t)npat * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
@@ -688,6 +799,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     int64_t bpat = -1;
     for (int i = 0; i < grid; ++i) {                     // argmin with first-index tie-break (Opt.jl:96)
         if (bp[(size_t)i] < 0) continue;
+        bp[(size_t)i] = reference_pattern(c, bp[(size_t)i]);
         if (bpat < 0 || bo[(size_t)i] < bobj || (bo[(size_t)i] == bobj && bp[(size_t)i] < bpat)) { bobj = bo[(size_t)i]; bpat = bp[(size_t)i]; }
     }
     if (best_obj) *best_obj = bobj;
@@ -888,6 +1000,22 @@ partls_status partls_get_vetoes(const partls_ctx *c, int64_t *vetoes)
 {
     if (!c || !vetoes) { set_error("partls_get_vetoes: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *vetoes = (int64_t)c->last_vetoes;
+    return PARTLS_OK;
+}
+
+partls_status partls_opt_bit_order(partls_ctx *c, int64_t *gbit, double *flip_cost)
+{
+    if (!c || !c->prepared) { set_error("partls_opt_bit_order: context not prepared"); return PARTLS_ERR_STATE; }
+    if (!gbit) { set_error("partls_opt_bit_order: gbit is NULL"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    if (!c->order_ready) {
+        partls_status st = calibrate_bit_order(c);
+        if (st != PARTLS_OK) return st;
+    }
+    for (int k = 0; k < c->kbits; ++k) {
+        gbit[k] = c->order.gbit[k];
+        if (flip_cost) flip_cost[k] = c->flip_cost.empty() ? -1.0 : c->flip_cost[(size_t)k];
+    }
     return PARTLS_OK;
 }
 

@@ -45,8 +45,11 @@ struct SweepParams {
     // tableau variable v is node_code[c * node_ld + v]:  +1 (w_v >= 0), -1 (w_v <= 0), 0 (w_v = 0: zero multiplier, or both
     // sign constraints of an overlapping partition), 2 (free: BnB's not yet branched groups, BnB.jl:70-79).  Per VARIABLE, not
     // per group: Alt's multipliers sum_k P[m,k] beta_k (Alt.jl:80-81) and BnB's accumulated constraints (BnB.jl:120-121) are
-    // not functions of a group sign pattern once a feature sits in two groups.  chain_len must be 1.  Outputs per node:
+    // not functions of a group sign pattern once a feature sits in two groups.  Outputs per node:
     // node_sol[c * node_ld + v] = scaled solution (0 for nonbasic), node_obj2[c] = objective^2.
+    // chain_len is 1 everywhere except in the register kernel's bit-order calibration (api.hip: calibrate_bit_order): there chain c
+    // solves the nodes c * chain_len + 0, 1, ... one after the other, each warm-started from its predecessor's tableau, node_sol /
+    // node_obj2 describe the LAST node of the chain, and node_piv[c * chain_len + i] = pivots of the workgroup up to node i.
     const int8_t *node_code;
     double *node_sol;
     double *node_obj2;
@@ -56,6 +59,7 @@ struct SweepParams {
     // winner's iterative refinement uses as its solver (api.hip: refine_solution)
     double *node_tab;
     int8_t *node_basic;
+    unsigned *node_piv;          // optional, register kernel only (see above)
     // cooperative single-node kernel only: continue from the tableau / basis left in `scratch` by the previous launch
     // (warm start of consecutive Alt alpha-steps) instead of reloading T0
     int resume;
@@ -81,6 +85,12 @@ hipError_t launch_gram(const double *X, int64_t N, int64_t M, int64_t ldX, const
 // perm[i] = augmented-Gram index of tableau variable i (variables are grouped by partition so a flip touches few tiles)
 hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, int free_intercept,
                        const int *perm, double *scale, double *Tfull, int n, hipStream_t s);
+
+// bit-order calibration (misc.hip): node codes of the calibration walks, and all_opt from internal to reference pattern order
+struct BitOrder { uint8_t gbit[40]; };                  // group k of the reference sits on bit gbit[k] of the internal pattern
+int        walk_flipped_bit(int chain, int step, int kbits, int seg_len, int nseg);
+hipError_t launch_walk_codes(const uint64_t *mask, int n, int kbits, int chains, int L, int seg_len, int nseg, int8_t *codes, hipStream_t s);
+hipError_t launch_pattern_gather(const double *in, int64_t npat, int kbits, const BitOrder &order, double *out, hipStream_t s);
 
 // residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
 // beta-step system of fit(Alt): Hg[k * (Kp + 1) + k2] = H[k][k2] (k2 < Kp), g[k] (k2 = Kp); GA is (M + 1) x Kp scratch

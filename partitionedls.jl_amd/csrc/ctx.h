@@ -56,6 +56,8 @@ struct partls_knobs {
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
+    int bit_order = 0;           // PARTLS_BIT_ORDER: 0 automatic (calibrate when the sweep is long enough to repay it), "identity" = 1
+                                 // (group k on Gray bit k), "calibrate" = 2 (always measure; small problems in the tests)
 };
 
 struct partls_ctx {
@@ -82,7 +84,8 @@ struct partls_ctx {
     // gram
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD /* + maskTabP, permP: one upload */, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
-        wdev, partial, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic, altA, altGA, altHg;
+        wdev, partial, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic, altA, altGA, altHg,
+        nodePiv, maskInt, allOptRef;
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
     std::vector<double> hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
@@ -90,6 +93,12 @@ struct partls_ctx {
     std::vector<int> perm;
     std::vector<uint64_t> mask_tab;
     bool use_reg = false;
+    // Opt sweep: which group sits on which bit of the Gray index (calibrate_bit_order, once per prepare, on the first sweep).
+    // The boundary speaks the reference's pattern index (group k = bit k, Opt.jl:4-12) everywhere; only the sweep kernel and the
+    // Gray-index ranges of partls_opt_sweep live in the internal order.
+    partls::BitOrder order{};
+    bool order_ready = false, order_identity = true;
+    std::vector<double> flip_cost;                 // measured pivots per flip of group k (empty when not calibrated)
     double tol = 0.0;
     unsigned long long last_pivots = 0, last_vetoes = 0, last_blocks = 0;
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve

@@ -127,6 +127,54 @@ hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Bit-order calibration of the Opt sweep (api.hip: calibrate_bit_order).  Bit b of the Gray index flips in 2^-(b+1) of all
+// transitions, so which group sits on which bit decides how many variables the sweep exchanges: measured on C3, the same 2^20
+// subproblems cost 16.9 M pivots / 74.9 ms in one order and 13.5 M / 52.2 ms in another.  The flip cost of a group is measured,
+// not guessed: chain c starts from a pseudo-random pattern and flips the groups of its segment one after the other.
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ static inline uint64_t walk_base(int chain, int kbits)
+{
+    return sm64(0xB17C0DE5ULL + (uint64_t)chain) & ((kbits >= 64) ? ~0ULL : ((1ULL << kbits) - 1));
+}
+int walk_flipped_bit(int chain, int step, int kbits, int seg_len, int nseg)       // step >= 1 flips this group
+{
+    return ((chain % nseg) * seg_len + step - 1) % kbits;
+}
+// codes[(c * L + i) * n + v]: constraint of tableau variable v at step i of chain c (sign of its multiplier, Opt.jl:28-29)
+__global__ void walk_codes_kernel(const uint64_t *__restrict__ mask, int n, int kbits, int L, int seg_len, int nseg,
+                                  int8_t *__restrict__ codes)
+{
+    const int c = blockIdx.x / L, i = blockIdx.x - c * L;
+    uint64_t pat = walk_base(c, kbits);
+    for (int j = 1; j <= i; ++j) pat ^= 1ULL << (((c % nseg) * seg_len + j - 1) % kbits);
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+        const uint64_t m = mask[v];
+        const int f = 2 * __popcll(m & pat) - __popcll(m);
+        codes[(size_t)blockIdx.x * n + v] = (int8_t)((f > 0) - (f < 0));
+    }
+}
+hipError_t launch_walk_codes(const uint64_t *mask, int n, int kbits, int chains, int L, int seg_len, int nseg, int8_t *codes, hipStream_t s)
+{
+    hipLaunchKernelGGL(walk_codes_kernel, dim3(chains * L), dim3(256), 0, s, mask, n, kbits, L, seg_len, nseg, codes);
+    return hipGetLastError();
+}
+
+// all_opt leaves the sweep indexed by the INTERNAL pattern (group k on bit gbit[k]); the boundary indexes it by the reference's
+__global__ void pattern_gather_kernel(const double *__restrict__ in, int64_t npat, int kbits, BitOrder order, double *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // reference pattern
+    if (r >= npat) return;
+    uint64_t q = 0;
+    for (int k = 0; k < kbits; ++k) q |= (((uint64_t)r >> k) & 1ULL) << order.gbit[k];
+    out[r] = in[q];
+}
+hipError_t launch_pattern_gather(const double *in, int64_t npat, int kbits, const BitOrder &order, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(pattern_gather_kernel, dim3((unsigned)((npat + 255) / 256)), dim3(256), 0, s, in, npat, kbits, order, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // beta-step system of fit(Alt) in Gram form (Alt.jl:109-110):  H = A' Greg A,  g = A' c  with  A = Po o alpha  ((M+1) x K').
 // Two tiny kernels with fixed summation orders (run-to-run reproducible, no atomics):
 //   1. GA[m][k2] = sum_{m2 in group k2} Greg[m][m2] alpha_m2          (one workgroup per row m, lane = k2)

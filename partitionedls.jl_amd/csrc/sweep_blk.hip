@@ -302,7 +302,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             int f;
             if constexpr (NODE) {                                   // node mode: chain index = node index, per-variable codes
                 pat = (uint64_t)chain;
-                const int code = has_var ? (int)p.node_code[(size_t)chain * p.node_ld + tid] : 0;
+                const int code = has_var ? (int)p.node_code[((size_t)chain * clen + gi) * p.node_ld + tid] : 0;   // a chain of nodes: warm start
                 isfree = code == 2;
                 f = isfree ? 0 : code;
             } else {
@@ -487,6 +487,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             // pattern, unless every pattern's objective is wanted
             const double obj2 = corner > 0.0 ? corner : 0.0;
             // bookkeeping of the finished pattern: by the last thread — its wave owns no panel row and has slack, wave 0 has none
+            if constexpr (NODE) {                                     // chain of nodes (bit-order calibration): pivots so far, per step
+                if (p.node_piv && tid == 0) p.node_piv[(size_t)chain * clen + gi] = npiv;
+            }
             if (p.all_opt && tid == THREADS - 1) p.all_opt[pat] = sqrt(obj2);
             if (tid == THREADS - 1) {                                // lexicographic (objective, pattern) minimum: argmin's first-index rule
                 const double bo = s_best[0];

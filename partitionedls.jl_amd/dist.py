@@ -13,14 +13,28 @@ def shard_range(npat, rank, world):
     return rank * npat // world, (rank + 1) * npat // world
 
 
-def allreduce_argmin(obj, pat, device=None, group=None):
-    """(objective, pattern) of the global lexicographic minimum. `pat < 0` means this rank has no candidate."""
+def order_key(gbit):
+    """A number every rank of a sharded sweep must agree on: the Gray-index ranges of shard_range only partition the pattern space
+    when all ranks visit it in the same order (Context.bit_order).  Exact in float64 (it rides in the objective all-reduce)."""
+    import zlib
+    import numpy as np
+    return float(zlib.crc32(np.asarray(gbit, dtype=np.int64).tobytes()))
+
+
+def allreduce_argmin(obj, pat, device=None, group=None, order_key=None):
+    """(objective, pattern) of the global lexicographic minimum. `pat < 0` means this rank has no candidate.
+    order_key (optional, see order_key()): checked for equality across the ranks inside the same all-reduce."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return obj, pat
-    o = torch.tensor([obj if pat >= 0 else float("inf")], dtype=torch.float64, device=device)
+    key = 0.0 if order_key is None else float(order_key)
+    o = torch.tensor([obj if pat >= 0 else float("inf"), key, -key], dtype=torch.float64, device=device)
     dist.all_reduce(o, op=dist.ReduceOp.MIN, group=group)
+    o = o.cpu()
+    if float(o[1]) != -float(o[2]):
+        raise RuntimeError("sharded Opt sweep: the ranks visit the patterns in different orders (Context.bit_order differs), "
+                           "so their Gray-index ranges do not partition the pattern space; prepare the same problem on every rank")
     gmin = float(o[0])
     i = torch.tensor([pat if (pat >= 0 and obj == gmin) else NO_CANDIDATE], dtype=torch.int64, device=device)
     dist.all_reduce(i, op=dist.ReduceOp.MIN, group=group)

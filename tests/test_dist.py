@@ -58,6 +58,41 @@ def test_allreduce_argmin_gloo_world2(partls):
         assert [tuple(x) for x in out[r]] == expect
 
 
+def _order_worker(rank, world, port, gbits, out):
+    import torch.distributed as dist
+    import partls_amd
+    pls = partls_amd.package()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = []
+    for per_rank in gbits:
+        try:
+            res.append(pls.dist.allreduce_argmin(1.0 + rank, 7 + rank, order_key=pls.dist.order_key(per_rank[rank])))
+        except RuntimeError as e:
+            res.append("mismatch" if "different orders" in str(e) else repr(e))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_sharded_sweep_refuses_ranks_with_different_visiting_orders(partls):
+    """Gray-index ranges partition the pattern space only when every rank visits it in the same order (the group -> Gray-bit
+    assignment a context calibrates): the key of the order rides in the objective all-reduce and a mismatch raises on every rank."""
+    import torch.multiprocessing as mp
+    same = [3, 0, 2, 1]
+    gbits = [[same, same], [same, [3, 0, 1, 2]]]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, gbits, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert tuple(out[r][0]) == (1.0, 7) and out[r][1] == "mismatch"
+    assert partls.dist.order_key(same) == partls.dist.order_key(list(same)) != partls.dist.order_key([0, 1, 2, 3])
+
+
 # ---- BnB: frontier batches sharded across ranks (dist.bnb_search); the bound function here is the CPU oracle's NNLS -----------
 def _bnb_problem():
     import numpy as np

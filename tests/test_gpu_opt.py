@@ -180,3 +180,79 @@ def test_errors(partls):
         ctx.opt_prepare_device(d.data_ptr(), d.data_ptr(), 4, 3, 3, np.array([[1, 0], [1, 0], [0, 1]]))          # ldX < N
     assert ei.value.status == partls.lowlevel.ERR_BAD_ARG
     ctx.close()
+
+
+# ---- visiting order of the sweep: which group sits on which Gray bit (calibrated on long enumerations) ---------------------------
+def _ctx_with_order(partls, monkeypatch, mode):
+    """a private context whose PARTLS_BIT_ORDER knob (read once at partls_create) is `mode`"""
+    monkeypatch.setenv("PARTLS_BIT_ORDER", mode)
+    return partls.Context(0)
+
+
+def _order_problem(seed=11, N=400, M=45, K=9, empty_group=None):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, M))
+    P = np.zeros((M, K), dtype=np.int64)
+    groups = [k for k in range(K) if k != empty_group]
+    P[np.arange(M), np.array(groups)[rng.integers(0, len(groups), size=M)]] = 1
+    sizes = P.sum(axis=0)
+    w = rng.standard_normal(M) * (rng.random(M) < 0.6)
+    y = X @ w + 0.5 + 0.3 * rng.standard_normal(N)
+    return np.asfortranarray(X), y, np.asfortranarray(P), sizes
+
+
+def test_calibrated_order_visits_the_same_subproblems(partls, oracle, monkeypatch):
+    """The sweep may put any group on any Gray bit (it measures the flip cost of every group and gives the cheap ones the fast bits);
+    the boundary keeps the reference's pattern index (Opt.jl:4-12): per-pattern objectives, winner and model are those of the plain
+    order and of the oracle, and shards of the Gray-index space still cover every pattern exactly once."""
+    X, y, P, _ = _order_problem()
+    flags = partls.lowlevel.OPT_FAITHFUL_INTERCEPT
+    res = {}
+    for mode in ("identity", "calibrate"):
+        ctx = _ctx_with_order(partls, monkeypatch, mode)
+        ctx.opt_prepare(X, y, P, 0.0, flags)
+        gbit, cost = ctx.bit_order()
+        npat = ctx.num_patterns()
+        bo, bp, allo, unconv = ctx.opt_sweep(0, -1, want_all=True)
+        assert unconv == 0
+        parts = [ctx.opt_sweep(*partls.dist.shard_range(npat, r, 3), want_all=True) for r in range(3)]
+        assert min((p[0], p[1]) for p in parts)[1] == bp
+        # every pattern is visited by exactly one shard (entries outside a shard are NaN), with the full sweep's value up to the
+        # round-off of a different chain path
+        seen = np.stack([~np.isnan(p[2]) for p in parts])
+        assert np.all(seen.sum(axis=0) == 1)
+        assert [int(v.sum()) for v in seen] == [b - a for a, b in (partls.dist.shard_range(npat, r, 3) for r in range(3))]
+        np.testing.assert_allclose(np.nansum(np.stack([p[2] for p in parts]), axis=0), allo, rtol=1e-9, atol=1e-10)
+        res[mode] = dict(gbit=gbit, cost=cost, bo=bo, bp=bp, allo=allo.copy(), model=ctx.opt_finish(bp))
+        ctx.close()
+    K1 = P.shape[1] + 1
+    assert list(res["identity"]["gbit"]) == list(range(K1)) and np.all(res["identity"]["cost"] == -1.0)
+    g = res["calibrate"]["gbit"]
+    assert sorted(g) == list(range(K1)) and list(g) != list(range(K1))         # a real permutation on this problem
+    c = res["calibrate"]["cost"]
+    assert np.all(c >= 0) and np.all(np.diff(c[np.argsort(g)]) >= 0)          # cheaper groups sit on faster bits
+    np.testing.assert_allclose(res["calibrate"]["allo"], res["identity"]["allo"], rtol=1e-9, atol=1e-10)
+    assert res["calibrate"]["bp"] == res["identity"]["bp"]
+    for u, v in zip(res["calibrate"]["model"], res["identity"]["model"]):
+        np.testing.assert_allclose(u, v, rtol=1e-9, atol=1e-10)
+    ref = oracle.fit_opt(X, y, P, 0.0, return_all=True)
+    np.testing.assert_allclose(res["calibrate"]["allo"], ref["all_opt"], rtol=1e-8, atol=1e-9)
+    assert res["calibrate"]["model"][4] == ref["best_index"]
+
+
+def test_calibrated_order_empty_group_and_first_index_tie(partls, oracle, monkeypatch):
+    """A group without features costs nothing to flip, so the calibration gives it the fastest bit; its two patterns tie exactly and
+    best_index must still be the reference's first index (Opt.jl:96), whatever the internal order."""
+    X, y, P, sizes = _order_problem(seed=12, K=8, empty_group=5)
+    assert sizes[5] == 0
+    ctx = _ctx_with_order(partls, monkeypatch, "calibrate")
+    ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    gbit, cost = ctx.bit_order()
+    assert cost[5] == 0.0 and gbit[5] == 0
+    bo, bp, allo, _ = ctx.opt_sweep(0, -1, want_all=True)
+    a, b, t, opt, bi = ctx.opt_finish(bp)
+    ctx.close()
+    ref = oracle.fit_opt(X, y, P, 0.0, return_all=True)
+    assert bi == ref["best_index"] and not (bi >> 5) & 1
+    np.testing.assert_allclose(allo, ref["all_opt"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(allo[np.arange(len(allo)) | (1 << 5)], allo[np.arange(len(allo)) & ~(1 << 5)], rtol=1e-12)
