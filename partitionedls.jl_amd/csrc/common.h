@@ -47,7 +47,8 @@ struct SweepParams {
     // per group: Alt's multipliers sum_k P[m,k] beta_k (Alt.jl:80-81) and BnB's accumulated constraints (BnB.jl:120-121) are
     // not functions of a group sign pattern once a feature sits in two groups.  Outputs per node:
     // node_sol[c * node_ld + v] = scaled solution (0 for nonbasic), node_obj2[c] = objective^2.
-    // chain_len is 1 everywhere except in the register kernel's bit-order calibration (api.hip: calibrate_bit_order): there chain c
+    // chain_len is 1 everywhere except in the bit-order calibration (api.hip: calibrate_bit_order; register and one-workgroup
+    // global-memory kernel): there chain c
     // solves the nodes c * chain_len + 0, 1, ... one after the other, each warm-started from its predecessor's tableau, node_sol /
     // node_obj2 describe the LAST node of the chain, and node_piv[c * chain_len + i] = pivots of the workgroup up to node i.
     const int8_t *node_code;
@@ -59,7 +60,7 @@ struct SweepParams {
     // winner's iterative refinement uses as its solver (api.hip: refine_solution)
     double *node_tab;
     int8_t *node_basic;
-    unsigned *node_piv;          // optional, register kernel only (see above)
+    unsigned *node_piv;          // optional (see above)
     // cooperative single-node kernel only: continue from the tableau / basis left in `scratch` by the previous launch
     // (warm start of consecutive Alt alpha-steps) instead of reloading T0
     int resume;

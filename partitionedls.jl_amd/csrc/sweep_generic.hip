@@ -65,7 +65,8 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
 
         for (int64_t g = g0; g < g1; ++g) {
             uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
-            const int8_t *code = p.node_code ? p.node_code + (size_t)chain * p.node_ld : nullptr;     // node mode: per-variable codes
+            // node mode: per-variable codes; a chain of nodes (bit-order calibration) warm-starts node i from node i - 1
+            const int8_t *code = p.node_code ? p.node_code + ((size_t)chain * p.chain_len + (size_t)(g - g0)) * p.node_ld : nullptr;
             if (code) pat = (uint64_t)chain;
             for (int i = tid; i < n; i += GEN_THREADS) s_blocked[i] = 0;
             __syncthreads();
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
             const double obj = sqrt(obj2 > 0.0 ? obj2 : 0.0);
             if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
             if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
+            if (p.node_piv && code && tid == 0) p.node_piv[(size_t)chain * p.chain_len + (size_t)(g - g0)] = (unsigned)npiv;
             __syncthreads();
         }
         if (p.node_sol) {

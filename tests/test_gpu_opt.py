@@ -256,3 +256,19 @@ def test_calibrated_order_empty_group_and_first_index_tie(partls, oracle, monkey
     assert bi == ref["best_index"] and not (bi >> 5) & 1
     np.testing.assert_allclose(allo, ref["all_opt"], rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(allo[np.arange(len(allo)) | (1 << 5)], allo[np.arange(len(allo)) & ~(1 << 5)], rtol=1e-12)
+
+
+def test_calibrated_order_on_the_global_memory_kernel(partls, oracle, monkeypatch):
+    """n = 331 > 320 tableau variables: the sweep and the calibration's chains of nodes run on sweep_generic.hip"""
+    X, y, P, _ = _order_problem(seed=13, N=700, M=330, K=5)
+    ctx = _ctx_with_order(partls, monkeypatch, "calibrate")
+    ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    gbit, cost = ctx.bit_order()
+    assert sorted(gbit) == list(range(6)) and np.all(cost >= 0) and np.all(np.diff(cost[np.argsort(gbit)]) >= 0)
+    bo, bp, allo, unconv = ctx.opt_sweep(0, -1, want_all=True)
+    a, b, t, opt, bi = ctx.opt_finish(bp)
+    ctx.close()
+    ref = oracle.fit_opt(X, y, P, 0.0, return_all=True)
+    assert unconv == 0 and bi == ref["best_index"]
+    np.testing.assert_allclose(allo, ref["all_opt"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(opt, ref["opt"], rtol=1e-9)
