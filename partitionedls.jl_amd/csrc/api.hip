@@ -600,7 +600,7 @@ int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared)
 
 // Which group sits on which bit of the Gray index.  Bit b flips in 2^-(b+1) of all transitions and a flip exchanges roughly the
 // variables of its group that carry signal, so the cheap groups belong on the fast bits: on C3 the reference's order (group k on
-// bit k) costs 16.9 M pivots / 74.9 ms, the measured-cost order 12.9 M / 49 ms for the same 2^20 subproblems.  The cost of a flip
+// bit k) costs 16.9 M pivots / 74.9 ms, the measured-cost order 13.2 M / 51.0 ms for the same 2^20 subproblems.  The cost of a flip
 // is MEASURED on the prepared problem: `ncu` chains of nodes on the kernel the sweep will use, chain c solving a pseudo-random pattern from
 // scratch and then flipping the groups of its half of the bits one after the other (each node warm-started from its predecessor,
 // exactly as in the sweep); pivots per flip are averaged per group.  Wall time = one chain = (8 + K'/2) patterns' worth, paid once
