@@ -167,7 +167,10 @@ def main():
         out["scaling"] = "strong"
         out["config"] = {"workload": f"{args.config}: fit({'Opt' if kind == 'opt' else 'Opt enumeration + BnB'}) N={N} D={D} K={K}, "
                                      f"{npat} sign patterns ({'2^(K+1) faithful' if args.faithful else '2^K, free intercept'}), eta=0",
-                         "seed": seed, "sharding": f"gray-index range / {world} ranks"}
+                         "seed": seed, "sharding": f"gray-index range / {world} ranks",
+                         "enumeration": "every one of the sign patterns is solved to KKT optimality in every step; they are visited along Gray-code "
+                                        "chains with the groups assigned to the Gray bits by their measured flip cost (calibration inside "
+                                        "every step: kernels_ms.bit_order_calibration; 0 = the enumeration is too short to repay it)"}
         # dominant kernel = the sweep; its launch processes this rank's shard; duration from HIP events on the library's stream
         sweep_avg_s = avg("t_sweep") * 1e-3
         solves_per_launch = res["local"]
