@@ -85,7 +85,8 @@ partls_status partls_opt_finish(partls_ctx *ctx, int64_t pattern,
  * Opt.jl:89, and its optval (Opt.jl:90).  Needs a prepared context. */
 partls_status partls_opt_pattern(partls_ctx *ctx, int64_t pattern, double *raw_alpha, double *optval);
 /* visiting order of the sweep: gbit[k] = Gray-index bit that carries group k (K' entries; identity unless calibrated);
- * flip_cost (optional, K' doubles): measured pivots per flip of group k, -1 when the calibration did not run (sweeps too short
+ * flip_cost (optional, K' doubles): measured cost of a flip of group k in pivot equivalents (pivots + weighted block pivots and
+ * extra KKT scans; exact counts, no timing), -1 when the calibration did not run (sweeps too short
  * to repay it, PARTLS_BIT_ORDER=identity); gbit stays the identity when the measured costs promise less than 2 % fewer pivots.  Runs the calibration if no sweep has done so yet.  Ranks of a sharded
  * sweep must hold the same gbit (partitionedls.jl_amd/dist.py checks it inside its first all-reduce). */
 partls_status partls_opt_bit_order(partls_ctx *ctx, int64_t *gbit, double *flip_cost);

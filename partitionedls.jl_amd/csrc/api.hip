@@ -543,6 +543,8 @@ partls_status partls_create(int device, partls_ctx **out)
     if (const char *e = getenv("PARTLS_GRAM_CR")) c->knobs.gram_cr = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_ROWS")) c->knobs.coop_rows = atoi(e);
     if (const char *e = getenv("PARTLS_BIT_ORDER")) c->knobs.bit_order = !strcmp(e, "identity") ? 1 : (!strcmp(e, "calibrate") ? 2 : 0);
+    if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
+    if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
@@ -625,7 +627,7 @@ static partls_status calibrate_bit_order(partls_ctx *c)
     const size_t steps = (size_t)chains * L;
 
     PARTLS_HIP_CHECK(c->nodeCode.ensure(steps * (size_t)n));
-    PARTLS_HIP_CHECK(c->nodePiv.ensure((steps + 8) * sizeof(unsigned)));
+    PARTLS_HIP_CHECK(c->nodePiv.ensure((3 * steps + 8) * sizeof(unsigned)));
     PARTLS_HIP_CHECK(c->nodeSol.ensure((4 + (size_t)chains + (size_t)chains * n) * sizeof(double)));
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 2 * 4096)));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
@@ -643,11 +645,11 @@ static partls_status calibrate_bit_order(partls_ctx *c)
     p.n_unconverged = c->nodePiv.as<unsigned long long>();
     p.node_code = c->nodeCode.as<int8_t>();
     p.node_obj2 = c->nodeSol.as<double>() + 4; p.node_sol = c->nodeSol.as<double>() + 4 + chains; p.node_ld = n;
-    p.node_piv = c->nodePiv.as<unsigned>() + 8;
+    p.node_piv = c->nodePiv.as<unsigned>() + 8;                    // 3 counters per step
     PARTLS_HIP_CHECK(launch_any_sweep(c, p, chains));
     t_end(c, PARTLS_T_CALIB);
-    std::vector<unsigned> piv(steps + 8);
-    PARTLS_HIP_CHECK(hipMemcpyAsync(piv.data(), c->nodePiv.p, (steps + 8) * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned> piv(3 * steps + 8);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(piv.data(), c->nodePiv.p, (3 * steps + 8) * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
     c->coop_state_valid = false;
@@ -656,12 +658,22 @@ static partls_status calibrate_bit_order(partls_ctx *c)
     std::memcpy(&unconv, piv.data(), sizeof(unconv));
     if (unconv) return PARTLS_OK;                            // a walk hit the pivot cap: the sample says nothing, keep the plain order
 
+    // Cost of a flip in pivot equivalents.  On the register kernel a pattern's cycles split (stamp build) into ~730 + 4.4 NS
+    // per pivot (panel step + update; NS = tile slots), ~4 400 per block pivot (gather, scatter, the update's start, barrier waits) and
+    // ~2 100 per KKT scan beyond the first, which every pattern pays: a group whose variables straddle tile columns so that a flip takes
+    // three blocks instead of two costs as much more as four extra pivots would.  All three counts are exact (no timing), so the
+    // order stays a deterministic function of the data.
+    const double ns = c->use_reg ? 0.5 * c->T * (c->T + 1) : 0.0;
+    const double per_pivot = 730.0 + 4.4 * ns;
+    const double w_block = c->use_reg ? c->knobs.cal_wb * 4400.0 / per_pivot : 0.0, w_scan = c->use_reg ? c->knobs.cal_ws * 2100.0 / per_pivot : 0.0;
     std::vector<double> cost((size_t)kb, 0.0);
     std::vector<int> cnt((size_t)kb, 0);
     for (int ch = 0; ch < chains; ++ch)
         for (int i = 1; i < L; ++i) {
             const int k = walk_flipped_bit(ch, i, kb, seg_len, nseg);
-            cost[(size_t)k] += (double)(piv[8 + (size_t)ch * L + i] - piv[8 + (size_t)ch * L + i - 1]);
+            const unsigned *now = &piv[8 + 3 * ((size_t)ch * L + i)], *was = now - 3;
+            const double scans = (double)(now[2] - was[2]);
+            cost[(size_t)k] += (double)(now[0] - was[0]) + w_block * (double)(now[1] - was[1]) + w_scan * (scans > 1.0 ? scans - 1.0 : 0.0);
             ++cnt[(size_t)k];
         }
     for (int k = 0; k < kb; ++k) cost[(size_t)k] = cnt[(size_t)k] ? cost[(size_t)k] / cnt[(size_t)k] : 0.0;

@@ -50,7 +50,8 @@ struct SweepParams {
     // chain_len is 1 everywhere except in the bit-order calibration (api.hip: calibrate_bit_order; register and one-workgroup
     // global-memory kernel): there chain c
     // solves the nodes c * chain_len + 0, 1, ... one after the other, each warm-started from its predecessor's tableau, node_sol /
-    // node_obj2 describe the LAST node of the chain, and node_piv[c * chain_len + i] = pivots of the workgroup up to node i.
+    // node_obj2 describe the LAST node of the chain, and node_piv[3 * (c * chain_len + i) + 0 / 1 / 2] = pivots / block pivots / KKT
+    // scans of the workgroup up to and including node i (the global-memory kernel reports pivots only).
     const int8_t *node_code;
     double *node_sol;
     double *node_obj2;

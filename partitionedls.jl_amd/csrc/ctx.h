@@ -56,6 +56,7 @@ struct partls_knobs {
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
+    double cal_wb = 1.0, cal_ws = 1.0;  // PARTLS_CAL_WB / PARTLS_CAL_WS: multipliers of the block / scan weights of the bit-order cost model (experiments)
     int bit_order = 0;           // PARTLS_BIT_ORDER: 0 automatic (calibrate when the sweep is long enough to repay it), "identity" = 1
                                  // (group k on Gray bit k), "calibrate" = 2 (always measure; small problems in the tests)
 };

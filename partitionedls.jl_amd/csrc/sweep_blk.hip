@@ -487,8 +487,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             // pattern, unless every pattern's objective is wanted
             const double obj2 = corner > 0.0 ? corner : 0.0;
             // bookkeeping of the finished pattern: by the last thread — its wave owns no panel row and has slack, wave 0 has none
-            if constexpr (NODE) {                                     // chain of nodes (bit-order calibration): pivots so far, per step
-                if (p.node_piv && tid == 0) p.node_piv[(size_t)chain * clen + gi] = npiv;
+            if constexpr (NODE) {                                     // chain of nodes (bit-order calibration): pivots, blocks, scans so far
+                if (p.node_piv && tid == 0) {
+                    unsigned *o = p.node_piv + 3 * ((size_t)chain * clen + gi);
+                    o[0] = npiv; o[1] = bc; o[2] = sc;
+                }
             }
             if (p.all_opt && tid == THREADS - 1) p.all_opt[pat] = sqrt(obj2);
             if (tid == THREADS - 1) {                                // lexicographic (objective, pattern) minimum: argmin's first-index rule
