@@ -17,7 +17,8 @@ One "step" = one pass of the hot path over the synthetic problem, inputs residen
   C4 (fit(Alt), N = 1M, D = 512): Gram build + the ALS loop (T = 200, eps = 1e-6 as Alt.jl:50-51; it converges long before T).
         One GPU per north_star: with N ranks every rank fits its own replica ("weak": replicas only, no collective).
         value = fits/s over all ranks; the roofline object is the Gram kernel's fp64-MFMA fraction.
-Rank 0 prints ONE JSON line (DESIGN.md §6 defines `roofline`, `roofline_fp64` and `cpu_baseline`).
+Rank 0 prints ONE JSON line (DESIGN.md §6 defines `roofline` (the binding fp64 bound), `roofline_hbm` (measured bytes),
+`nominal_hbm` (SURVEY §8(d)'s byte model) and `cpu_baseline`).
 """
 import argparse
 import json
@@ -181,20 +182,33 @@ def main():
         tiles = (n_tab + 15) // 16
         flops = res["pivots"] * (tiles * (tiles + 1) // 2) * 256 * 2
         fp64_tflops = flops / sweep_avg_s / 1e12
+        # HBM traffic of one sweep launch: PMC counters cannot be read inside this process, so the per-launch figure is the one the
+        # round's rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS command measured (tools/profile_r03.sh -> profiles/)
         traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_sweep_traffic.json")
-        if world == 1 and args.config == "C3" and not args.faithful and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            tsrc = "offline PMC (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this kernel, corrected per MI355X_MICROARCH.md), " \
-                   "profiles/r02_sweep_traffic.json — not measured in this run"
-        out["roofline"] = {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3,
-                           "algorithmic_bytes_per_solve": bytes_per_solve, "solves_per_launch": solves_per_launch,
-                           "note": "SURVEY §8(d) nominal bytes; the tableau is register-resident, so HBM is idle — see roofline_fp64"}
-        out["roofline_fp64"] = {"bound": "fp64 vector FMA", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": fp64_tflops / FP64_PEAK_TFLOPS, "pivots_per_launch": res["pivots"],
-                                "note": "the kernel's real bound: fp64 FMA issue of the rank-1 tableau updates"}
+        for tname in ("r03_sweep_traffic.json", "r02_sweep_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if world == 1 and args.config == "C3" and not args.faithful and os.path.exists(tpath):
+                traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+                tsrc = "offline PMC (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this kernel, corrected per MI355X_MICROARCH.md), " \
+                       f"profiles/{tname} — not measured in this run"
+                break
+        # The binding bound of the sweep is fp64 FMA issue: the tableau lives in registers and is never re-read from HBM, so every
+        # pivot costs one rank-1 update of the symmetric tableau = T(T+1)/2 tile slots x 256 FMAs, whatever the memory system does.
+        out["roofline"] = {"bound": "fp64-valu", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": fp64_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                           "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3, "pivots_per_launch": res["pivots"],
+                           "flop_per_pivot": (tiles * (tiles + 1) // 2) * 256 * 2, "solves_per_launch": solves_per_launch,
+                           "note": "algorithmic flops = principal pivots x tile slots x 256 x 2 (counted by the kernel) / HIP-event time of "
+                                   "the sweep launch; peak = 78.6 TFLOP/s fp64 vector (public datasheet; not in the on-image guide)"}
+        out["roofline_hbm"] = None if traffic is None else {
+            "bound": "hbm", "achieved": traffic / sweep_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": traffic / sweep_avg_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
+            "note": "MEASURED HBM bytes of the sweep launch (chain-start tableau loads and their scratch) / kernel time: HBM is idle"}
+        out["nominal_hbm"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_solve": bytes_per_solve,
+                              "note": "SURVEY §8(d) nominal bytes (G re-read per solve) x solves / kernel time. NOT a roofline fraction: "
+                                      "warm-started Gray chains keep the tableau in registers, the kernel never moves these bytes, so "
+                                      "the figure can exceed 1"}
         out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "bit_order_calibration": avg("t_calib"),
                              "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
         out["gram"] = {"tflops_useful": gram_flops / (avg("t_gram") * 1e-3) / 1e12, "frac_of_fp64_mfma_peak":
@@ -233,7 +247,22 @@ def main():
                            "nodes_per_s": bounded / dt, "capped": bounded >= args.bnb_cap,
                            "incumbent": (mu if mu != float("inf") else None)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "alt":
-        out["cpu_baseline"] = cpu_baseline(args, seed, N, D, K, res, np)
+        # the sample of the CPU baseline: the GPU's winner + random patterns (reference indexing, K + 1 bits).  The device's answer for
+        # every one of them — from the SWEEP's own per-pattern output (all_opt of a faithful enumeration: what ranks the patterns) and
+        # from a single re-solve with the objective recomputed from the data (partls_opt_pattern) — is compared with the dense oracle:
+        # SURVEY §8(d) "per sampled pattern and for the global optimum"
+        npat_ref = 1 << (K + 1)
+        n = max(1, args.cpu_patterns)
+        sample = [int(res["best_index"])] + [int(v) for v in np.random.default_rng(0).integers(0, npat_ref, size=n - 1)]
+        if kind == "bnb":                                        # the BnB leg re-generated y: restore the config's problem
+            ctx.synth_device(seed, N, D, wstar, dX.data_ptr(), dy.data_ptr())
+            torch.cuda.synchronize()
+        ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
+        _, _, allopt, unc = ctx.opt_sweep(0, -1, want_all=True)
+        dev_sweep = [float(allopt[b]) for b in sample]
+        del allopt
+        dev_solve = [ctx.opt_pattern(b)[1] for b in sample]
+        out["cpu_baseline"] = cpu_baseline(args, seed, N, D, K, res, sample, dev_sweep, dev_solve, np)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
@@ -241,24 +270,29 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, seed, N, D, K, res, np):
+def cpu_baseline(args, seed, N, D, K, res, sample, dev_sweep, dev_solve, np):
     """A: the oracle in reference-faithful dense mode (Opt.jl:87-90 per pattern: column scaling + dense Lawson–Hanson on the
-    N x (D+1) matrix + objective) on a bounded sample that always includes the GPU's winner (whose objective is compared: the
-    fp64 objective gap).  B: the same NNLS on the QR-compressed problem — the CPU analogue of the Gram form — on 1 core and on
-    all workers.  Both run in spawned worker processes of oracle/cpu_baseline.py."""
+    N x (D+1) matrix + objective) on a bounded sample that always includes the GPU's winner; every sampled objective is compared
+    with the device's (the fp64 objective gap).  B: the same NNLS on the QR-compressed problem — the CPU analogue of the Gram
+    form — on 1 core and on all workers.  Both run in spawned worker processes of oracle/cpu_baseline.py."""
     from oracle import cpu_baseline as CB
     workers = args.cpu_workers or CB.default_workers()
     npat_ref = 1 << (K + 1)
-    n = max(1, args.cpu_patterns)
-    rng = np.random.default_rng(0)
-    sample = [int(res["best_index"])] + [int(v) for v in rng.integers(0, npat_ref, size=n - 1)]
+    n = len(sample)
     objs, wall, cpu_s, setup = CB.dense_sample(seed, N, D, K, sample, min(workers, n))
-    gap = abs(objs[0] - res["opt"]) / max(1.0, objs[0])
+    rel = lambda a, b: abs(a - b) / max(1.0, b)
+    gap = rel(res["opt"], objs[0])
+    gap_sweep = max(rel(a, b) for a, b in zip(dev_sweep, objs))
+    gap_solve = max(rel(a, b) for a, b in zip(dev_solve, objs))
     b1, bn, bsetup = CB.compressed_rates(seed, N, D, K, 64 if N * D > 5_000_000 else 256, workers)
     return {"value": n / wall, "unit": "solves/s", "cores": min(workers, n), "kind": "port",
             "sample": f"{n} of {npat_ref} patterns (winner + random), dense Lawson-Hanson per pattern as Opt.jl:87-90, "
                       f"C restatement of the reference algorithm (not Julia), one pattern per worker call; host has {os.cpu_count()} cores",
             "seconds": wall, "per_core_solves_per_s": n / cpu_s, "obj_gap_winner": gap, "oracle_opt_winner": float(objs[0]),
+            "obj_gap_sampled_max": gap_sweep, "obj_gap_sampled_max_resolved": gap_solve,
+            "obj_gap_note": "|device - oracle| / max(1, oracle) over the whole sample; `sampled_max`: the sweep's own per-pattern "
+                            "objective (all_opt of a faithful 2^(K+1) enumeration, Gram form); `resolved`: partls_opt_pattern "
+                            "(single solve, objective from the data); `winner`: the timed run's opt",
             "gram_form": {"what": "Baseline B (BASELINE.md §3.2): the same NNLS on the QR-compressed (D+2) x (D+1) problem, i.e. the "
                                   "data are read once as on the GPU; compression time not included",
                           "solves_per_s_1_core": b1, "solves_per_s_all_workers": bn, "workers": workers,

@@ -96,6 +96,39 @@ def test_c3_dense_oracle_objective_of_winner(partls, oracle):
     assert abs(opt - ref) <= 1e-9 * max(1.0, ref)
 
 
+def _sampled_patterns_vs_compressed_oracle(partls, oracle, seed, N, D, K, nsample):
+    """The sweep's own per-pattern objective (all_opt of the faithful 2^(K+1) enumeration) at `nsample` random patterns + the
+    winner against the oracle's Lawson–Hanson on the QR-compressed data — the loop body Opt.jl:87-90 per sampled pattern."""
+    ctx, dX, dy, P, ws = _device_problem(partls, seed, N, D, K)
+    ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    bo, bp, allopt, unconv = ctx.opt_sweep(0, -1, want_all=True)
+    assert unconv == 0 and len(allopt) == 1 << (K + 1) and not np.isnan(allopt).any()
+    assert bp == int(np.argmin(allopt)) and bo == allopt[bp]              # the running minimum IS the argmin of the per-pattern output
+    pats = np.unique(np.concatenate([[bp], np.random.default_rng(seed).integers(0, 1 << (K + 1), nsample)]))
+    dev = allopt[pats].copy()
+    del allopt
+    X, y, Ph, _ = oracle.synth(seed, N, D, K)                              # bit-identical to the device data (tested separately)
+    Xo, Po = oracle.homogeneous(X, Ph)
+    del X
+    R, z = oracle.compress(Xo, y)
+    del Xo
+    ref = oracle.opt_patterns(R, z, Po, pats)
+    np.testing.assert_allclose(dev, ref, rtol=1e-9)
+    # single re-solves of a few of them (objective recomputed from the data) agree as well
+    for b in pats[:4]:
+        assert abs(ctx.opt_pattern(int(b))[1] - ref[list(pats).index(b)]) <= 1e-9 * ref[list(pats).index(b)]
+
+
+def test_c3_sampled_patterns_vs_dense_oracle(partls, oracle):
+    """BASELINE config 3 (N=100k, D=256, K=20): 64 random patterns of the 2^21 + the winner, rtol 1e-9."""
+    _sampled_patterns_vs_compressed_oracle(partls, oracle, 20260003, 100_000, 256, 20, 64)
+
+
+def test_c5_sampled_patterns_vs_dense_oracle(partls, oracle):
+    """BASELINE config 5 (N=100k, D=256, K=24): 64 random patterns of the 2^25 + the winner, rtol 1e-9."""
+    _sampled_patterns_vs_compressed_oracle(partls, oracle, 20260005, 100_000, 256, 24, 64)
+
+
 def test_c5_bnb_equals_opt(partls):
     """BASELINE config 5 shape (N=100k, D=256, K=24): BnB optimum == Opt optimum (2^24 patterns), same model."""
     seed, N, D, K = 20260005, 100_000, 256, 24
