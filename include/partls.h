@@ -63,6 +63,32 @@ partls_status partls_fit_opt(partls_ctx *ctx, const double *X, int64_t N, int64_
                              const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
                              double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt);
 
+/* ---- fit(Opt) on several GPUs of one node, inside the library  — the loop Opt.jl:85-94 has no loop-carried state ---------
+ * One process, one host thread and one context per device.  Every device builds the Gram products from X (replicated upload),
+ * sweeps the Gray-index range [r * 2^K' / R, (r+1) * 2^K' / R) of the pattern space, and the global lexicographic minimum
+ * (objective, reference pattern index) — argmin's first-index rule, Opt.jl:96 — is taken with two RCCL all-reduces over xGMI:
+ * ncclMin on the objective, then ncclMin on the index masked to the minimisers (RCCL has no MINLOC).  The key of the
+ * visiting order rides in the first all-reduce; ranks that disagree on it fail with PARTLS_ERR_STATE instead of combining
+ * shards that do not partition the pattern space.  The winner is re-solved on the first device.
+ *   devices[ndev]: HIP device indices (devices == NULL: devices 0 .. ndev-1; ndev == 0: every visible device).
+ *   A list that names one device more than once (rehearsal of the R-rank control flow on a one-GPU box) cannot form an RCCL
+ *   communicator: its reduction runs through the host instead; everything else is the same code.
+ *   librccl.so.1 is loaded when the first communicator is needed (PARTLS_RCCL_LIB overrides the name), never for partls_fit_opt.
+ * partls_fit_opt_multi: arguments and outputs exactly as partls_fit_opt (all_opt: the shards' entries merged).
+ * partls_multi_context: the context of rank r (rank 0 holds the winner's problem after a fit: partls_opt_finish /
+ * partls_opt_pattern on it rebuild the models of returnAllSolutions, Opt.jl:99-101).  A partls_multi is not thread-safe. */
+typedef struct partls_multi partls_multi;
+partls_status partls_multi_create(const int *devices, int ndev, partls_multi **out);
+void          partls_multi_destroy(partls_multi *mc);
+int           partls_multi_size(const partls_multi *mc);                 /* number of ranks (0 for NULL)                  */
+int           partls_multi_uses_rccl(const partls_multi *mc);            /* 1: reductions over RCCL, 0: host (see above)   */
+partls_ctx   *partls_multi_context(partls_multi *mc, int rank);          /* NULL when out of range                         */
+partls_status partls_fit_opt_multi(partls_multi *mc, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                                   const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
+                                   double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt);
+/* per-rank HIP-event time (ms) of stage `which` in the last partls_fit_opt_multi */
+partls_status partls_multi_get_timing(const partls_multi *mc, int rank, int which, double *ms);
+
 /* ---- staged form of the same path (multi-GPU sharding, device-resident inputs, benchmarking) ------------------------
  * prepare:  builds G = Xo'Xo, c = Xo'y, yy (fp64 MFMA), applies η, scales, lays the tableau out for the sweep.
  *           x_on_device != 0: X and y are DEVICE pointers (hipMalloc / torch) and stay owned by the caller.

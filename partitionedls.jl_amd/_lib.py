@@ -25,6 +25,14 @@ SYMBOLS = [
     ("partls_destroy", None, [C.c_void_p]),
     ("partls_fit_opt", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
                                  C.c_uint32, _dp, _dp, _dp, _dp, _ip, _dp]),
+    ("partls_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    ("partls_multi_destroy", None, [C.c_void_p]),
+    ("partls_multi_size", C.c_int, [C.c_void_p]),
+    ("partls_multi_uses_rccl", C.c_int, [C.c_void_p]),
+    ("partls_multi_context", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("partls_fit_opt_multi", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
+                                       C.c_uint32, _dp, _dp, _dp, _dp, _ip, _dp]),
+    ("partls_multi_get_timing", C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
     ("partls_opt_prepare", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_int, C.c_void_p, _i64, _i64,
                                      C.c_double, C.c_uint32]),
     ("partls_opt_sweep", C.c_int, [C.c_void_p, _i64, _i64, _dp, _ip, _dp, _ip]),

@@ -88,9 +88,9 @@ class Context:
         """Release the device objects now.  Also run for every live context by an atexit hook, i.e. BEFORE interpreter
         finalisation and before the HIP runtime (or a profiler layered on it) tears itself down — a context destroyed later,
         from a module-global's __del__ during exit(), made HIP calls into a dead runtime (round-1 rocprofv3 crash)."""
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):      # a view of a MultiContext's rank does not own the handle
             L.lib().partls_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -219,6 +219,76 @@ class Context:
         _check(L.lib().partls_synth_device(self._h, C.c_uint64(seed), N, D, _dp(ws), C.c_void_p(dX_ptr), C.c_void_p(dy_ptr)))
 
 
+class MultiContext:
+    """Owner of a partls_multi: fit(Opt) sharded over several GPUs of one node inside the library (one host thread and one
+    context per device, RCCL min-reduce; include/partls.h: partls_fit_opt_multi).  devices: None = every visible device, an int
+    n = devices 0..n-1, or a list of device indices (a list naming a device twice rehearses the R-rank control flow on one GPU:
+    its reduction then runs through the host)."""
+
+    def __init__(self, devices=None):
+        self._h = C.c_void_p()
+        if devices is None:
+            arr, n = None, 0
+        elif isinstance(devices, (int, np.integer)):
+            arr, n = None, int(devices)
+        else:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            n = len(devices)
+        _check(L.lib().partls_multi_create(arr, n, C.byref(self._h)))
+        self.generation = 0          # bumped by every fit (see _Solutions)
+        self.devices = [int(d) for d in devices] if arr is not None else list(range(self.size))
+        _live_contexts.add(self)
+
+    def close(self):
+        if self._h:
+            L.lib().partls_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return int(L.lib().partls_multi_size(self._h))
+
+    @property
+    def uses_rccl(self):
+        return bool(L.lib().partls_multi_uses_rccl(self._h))
+
+    def context(self, rank=0):
+        """Non-owning view of rank r's context (rank 0 holds the fitted problem: opt_finish / opt_pattern work on it)."""
+        h = L.lib().partls_multi_context(self._h, int(rank))
+        if not h:
+            raise IndexError("rank out of range")
+        view = Context.__new__(Context)
+        view._h, view.device, view.generation, view._borrowed, view._owner = C.c_void_p(h), None, 0, True, self
+        return view
+
+    def fit_opt(self, X, y, P, eta=0.0, flags=0, want_all=False):
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        P = np.asfortranarray(P, dtype=np.int64)
+        N, M = X.shape
+        K = P.shape[1]
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double(); bi = C.c_int64()
+        allopt = np.full(1 << (K + 1), np.nan) if want_all else None
+        self.generation += 1
+        _check(L.lib().partls_fit_opt_multi(self._h, X.ctypes.data, N, M, N, y.ctypes.data, P.ctypes.data, K, M, float(eta),
+                                            int(flags), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(bi),
+                                            _dp(allopt) if want_all else None))
+        self._shape = (N, M, K)
+        return a, b, t.value, o.value, bi.value, allopt
+
+    def timing(self, rank, which):
+        ms = C.c_double()
+        _check(L.lib().partls_multi_get_timing(self._h, int(rank), int(which), C.byref(ms)))
+        return ms.value
+
+
 def synth_truth(seed, D, K):
     """Partition matrix and true weights of the BASELINE.md §4 synthetic problem (host side, tiny)."""
     P = np.zeros((D, K), dtype=np.int64, order="F")
@@ -228,6 +298,7 @@ def synth_truth(seed, D, K):
 
 
 _default_ctx = {}
+_default_multi = {}
 _live_contexts = weakref.WeakSet()
 
 
@@ -239,12 +310,20 @@ def _close_all_contexts():
         except Exception:
             pass
     _default_ctx.clear()
+    _default_multi.clear()
 
 
 def default_context(device=0):
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
+
+
+def default_multi(devices=None):
+    key = devices if devices is None or isinstance(devices, (int, np.integer)) else tuple(int(d) for d in devices)
+    if key not in _default_multi:
+        _default_multi[key] = MultiContext(devices)
+    return _default_multi[key]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -289,22 +368,30 @@ def _marshal(X, y, P):
 
 
 class _Solutions:
-    """returnAllSolutions (Opt.jl:99-101): element b is (opt_b, PartLSFitResult_b); models are rebuilt on demand."""
+    """returnAllSolutions (Opt.jl:99-101): element b is (opt_b, PartLSFitResult_b); models are rebuilt on demand from the context
+    that holds the fitted problem.  They stay valid whatever is fitted afterwards, as in the reference: when a later fit has taken
+    the shared context over, the problem is prepared once more on a private context owned by this object."""
 
-    def __init__(self, ctx, all_opt, P):
-        self._ctx, self._all, self._P = ctx, all_opt, P
-        self._gen = ctx.generation       # the shared context may be re-prepared by a later fit: detect, never mis-answer
+    def __init__(self, ctx, all_opt, P, problem):
+        self._ctx, self._all, self._P, self._problem = ctx, all_opt, P, problem
+        self._owner = getattr(ctx, "_owner", ctx)      # a view of a MultiContext's rank 0: the owner counts the fits
+        self._gen = self._owner.generation
 
     def __len__(self):
         return len(self._all)
 
+    def _context(self):
+        if self._owner.generation != self._gen:        # the shared context now holds another problem
+            Xf, yf, Pf, eta, flags, device = self._problem
+            self._ctx = self._owner = Context(device)
+            self._ctx.opt_prepare(Xf, yf, Pf, eta, flags)
+            self._gen = self._ctx.generation
+        return self._ctx
+
     def __getitem__(self, b):
         if b < 0:
             b += len(self)
-        if self._ctx.generation != self._gen:
-            raise PartlsError(L.ERR_STATE, "the context of these solutions has been prepared for another problem since; "
-                                           "materialise the models you need (list(report.solutions)) before the next fit")
-        a, bt, t, opt, _ = self._ctx.opt_finish(b)
+        a, bt, t, opt, _ = self._context().opt_finish(b)
         return float(self._all[b]), PartLSFitResult(a, bt, t, self._P)
 
     def __iter__(self):
@@ -312,13 +399,14 @@ class _Solutions:
 
 
 def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="nnls", returnAllSolutions=False, rng=None,
-        alpha0=None, beta0=None, device=0, faithful_intercept=False, generic_kernel=False):
+        alpha0=None, beta0=None, device=0, devices=None, faithful_intercept=False, generic_kernel=False):
     """fit(::Type{Opt|Alt|BnB}, X, y, P; η, ...) -> (PartLSFitResult, None, Report)   [Opt.jl:73, Alt.jl:50, BnB.jl:30]
 
     η/eta: regularisation (default 0.0);  Alt: ϵ/eps (1e-6), T (100), rng (None | int seed | numpy Generator) or an
     explicit starting point alpha0[M+1], beta0[K+1];  Opt: returnAllSolutions.
     faithful_intercept=True enumerates the reference's 2^(K+1) patterns instead of 2^K with a free intercept
-    (same optimum).  nnlsalg is accepted for signature parity; the device solver is an exact active-set method.
+    (same optimum).  Opt, devices=... (None | count | list of device indices): the enumeration is sharded over those GPUs
+    inside the library (partls_fit_opt_multi: RCCL min-reduce), as the Julia drop-in does on a multi-GPU node.  nnlsalg is accepted for signature parity; the device solver is an exact active-set method.
     """
     if alg not in (Opt, Alt, BnB):
         raise TypeError("fit: first argument must be Opt, Alt or BnB")
@@ -335,6 +423,15 @@ def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="n
     if alg is Opt:
         flags = (L.OPT_FAITHFUL_INTERCEPT if (faithful_intercept or returnAllSolutions) else 0) | \
                 (L.OPT_GENERIC_KERNEL if generic_kernel else 0)
+        if devices is not None:
+            mc = default_multi(devices)
+            a, b, t, opt, bi, allopt = mc.fit_opt(Xf, yf, Pf, eta_v, flags, want_all=returnAllSolutions)
+            model = PartLSFitResult(a, b, t, Pout)
+            if returnAllSolutions:
+                c0 = mc.context(0)
+                c0._shape = (N, M, K)
+                return model, None, Report(solutions=_Solutions(c0, allopt, Pout, (Xf, yf, Pf, eta_v, flags, mc.devices[0])))
+            return model, None, Report(opt=opt, best_index=bi)
         ctx.opt_prepare(Xf, yf, Pf, eta_v, flags)
         bobj, bpat, allopt, unconv = ctx.opt_sweep(0, -1, want_all=returnAllSolutions)
         if unconv:
@@ -342,7 +439,7 @@ def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="n
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         model = PartLSFitResult(a, b, t, Pout)
         if returnAllSolutions:
-            return model, None, Report(solutions=_Solutions(ctx, allopt, Pout))
+            return model, None, Report(solutions=_Solutions(ctx, allopt, Pout, (Xf, yf, Pf, eta_v, flags, device)))
         return model, None, Report(opt=opt, best_index=bi)
     if alg is Alt:
         if alpha0 is None or beta0 is None:

@@ -197,7 +197,10 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     PARTLS_HIP_CHECK(c->nodeSol.ensure(out_words * sizeof(double)));
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * 4096));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
-    const bool coop = !c->use_reg && cnt == 1 && !c->knobs.no_coop;
+    // one large problem: many workgroups on a single global-memory tableau (sweep_coop.hip) — unless a previous attempt of this very
+    // call found the device too crowded for its grid barrier (`coop_fallback`, set below)
+    const bool coop = !c->use_reg && cnt == 1 && !c->knobs.no_coop && !c->coop_fallback;
+    c->coop_fallback = false;
     if (coop) {
         const size_t need = ((size_t)2 * ld * ld + (size_t)n / 8 + 2) * sizeof(double);  // two tableau images + basis flags + current image
         if (c->scratch.bytes < need) c->coop_state_valid = false;
@@ -248,7 +251,8 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         p.resume = (resume && c->coop_state_valid) ? 1 : 0;
         PARTLS_HIP_CHECK(c->gridCtr.ensure(64));
         p.grid_ctr = c->gridCtr.as<unsigned>();
-        c->coop_state_valid = true;
+        p.coop_fault = c->knobs.coop_fault;
+        c->coop_state_valid = false;                                   // until this launch is known to have completed
         // 6 rows per workgroup (measured at n = 513: 0.87 / 0.81 / 0.79 / 0.85 ms per alpha-step with 16 / 8 / 6 / 4): its 16 waves take
         // half a row each in the fused update (gj_apply); more workgroups than that only lengthen the grid barrier
         const int rows_wg = c->knobs.coop_rows > 0 ? c->knobs.coop_rows : 6;
@@ -274,6 +278,14 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     std::memcpy(counters, outw.data(), sizeof(counters));
+    if (coop && (counters[0] >> 40)) {
+        // grid-barrier timeout: some workgroups of the cooperative grid were not resident (the device is shared with another
+        // context or process).  Nothing of that attempt is used; the same node is solved again by ONE workgroup, which needs no
+        // co-residency (slower, never hangs).
+        c->coop_fallback = true;
+        return solve_nodes(c, codes, cnt, sols, obj2, unconv, false, want_tab);
+    }
+    if (coop) c->coop_state_valid = counters[0] == 0;
     std::copy(outw.begin() + 4, outw.begin() + 4 + (ptrdiff_t)cnt, obj2.begin());
     std::copy(outw.begin() + 4 + (ptrdiff_t)cnt, outw.end(), sols.begin());
     if (unconv) *unconv = counters[0];
@@ -546,6 +558,7 @@ partls_status partls_create(int device, partls_ctx **out)
     if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
+    if (const char *e = getenv("PARTLS_COOP_FAULT")) c->knobs.coop_fault = atoi(e);
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
     c->knobs.alt_trace = getenv("PARTLS_ALT_TRACE") != nullptr;
@@ -780,6 +793,8 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.n_unconverged = c->bestObj.as<unsigned long long>();
     p.n_pivots = c->bestObj.as<unsigned long long>() + 1;
     p.n_vetoes = c->bestObj.as<unsigned long long>() + 2;
+    for (int k = 0; k < 40; ++k) p.rbit.gbit[k] = (uint8_t)k;
+    if (!c->order_identity) for (int k = 0; k < c->kbits; ++k) p.rbit.gbit[c->order.gbit[k]] = (uint8_t)k;   // exact ties: first REFERENCE index
 
     t_begin(c, PARTLS_T_SWEEP);
     PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
@@ -855,8 +870,9 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     else full = (uint64_t)pattern;
     // A group without any feature leaves the subproblem unchanged: the reference then sees bitwise equal objectives for the two
     // patterns and argmin keeps the first, i.e. the one with that group's bit clear (Opt.jl:96)
+    // — and so does a group whose every feature is a null column (scale 0: never in a basis; the reference's X .* f' has +-0 columns)
     uint64_t used = 1ULL << c->K;
-    for (int64_t m = 0; m < c->M; ++m) used |= c->mask_aug[(size_t)m];
+    for (int i = 0; i < c->n; ++i) if (c->hScale[(size_t)i] != 0.0) used |= c->mask_tab[(size_t)i];
     full &= used;
     st = data_objective(c, w, opt);
     if (c->knobs.finish_trace) {

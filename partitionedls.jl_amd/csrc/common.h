@@ -24,6 +24,8 @@ void set_error(const char *fmt, ...);
 // ---------------------------------------------------------------------------------------------------------------------
 // sweep parameters (shared by the register-resident and the global-memory tableau kernels)
 // ---------------------------------------------------------------------------------------------------------------------
+struct BitOrder { uint8_t gbit[40]; };                  // group k of the reference sits on bit gbit[k] of the internal pattern
+
 struct SweepParams {
     int n;                       // tableau variables (features [+ intercept when it is sign-constrained])
     int kbits;                   // bits of the pattern space (K' = number of groups that carry a sign)
@@ -37,7 +39,9 @@ struct SweepParams {
     int max_rounds;              // cap on exchange rounds per pattern
     double *all_opt;             // optional [2^kbits] objective per pattern index
     double *best_obj;            // [gridDim.x] per-workgroup minimum objective
-    int64_t *best_pat;           // [gridDim.x] its pattern index (lexicographic tie-break on the index)
+    int64_t *best_pat;           // [gridDim.x] its pattern index (internal bit order; ties broken on the REFERENCE index, see rbit)
+    BitOrder rbit;               // chain mode: rbit.gbit[b] = the reference's bit (group) that internal pattern bit b carries.  Only
+                                 // exact objective ties read it: argmin keeps the first REFERENCE index (Opt.jl:96)
     unsigned long long *n_unconverged;   // patterns that hit max_rounds
     unsigned long long *n_pivots;        // total pivots on the (n+1)^2 tableau (diagnostics / flop accounting)
     unsigned long long *n_vetoes;        // entering pivots refused by the leave-one-out rule (diagnostics)
@@ -65,10 +69,28 @@ struct SweepParams {
     // cooperative single-node kernel only: continue from the tableau / basis left in `scratch` by the previous launch
     // (warm start of consecutive Alt alpha-steps) instead of reloading T0
     int resume;
-    unsigned *grid_ctr;          // multi-workgroup kernel: arrival counter of its grid barrier (zeroed by the launcher)
+    unsigned *grid_ctr;          // multi-workgroup kernel: arrival counter [0] and abort word [1] of its grid barrier (zeroed by the launcher)
+    int coop_fault;              // test hook (PARTLS_COOP_FAULT): the grid barrier expects this many arrivals too many, i.e. it can
+                                 // only time out — exercises the abort word and the host's one-workgroup fallback
 };
 
 // launchers (each returns hipError_t of the launch)
+// Exact objective ties (rare path): does internal pattern a come before internal pattern b in the reference's index order?  The
+// reference index of a pattern is sum_b bit_b << rbit[b]; of two patterns the one with a 0 in the differing bit of highest reference
+// weight is the smaller.
+__device__ __forceinline__ bool ref_index_less(unsigned long long a, unsigned long long b, const unsigned char *rbit)
+{
+    unsigned long long d = a ^ b;
+    int top = -1, at = 0;
+    while (d) {
+        const int i = __builtin_ctzll(d);
+        d &= d - 1;
+        const int r = rbit[i];
+        if (r > top) { top = r; at = i; }
+    }
+    return top >= 0 && !((a >> at) & 1ULL);
+}
+
 hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s);
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 320)
@@ -89,7 +111,6 @@ hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64
                        const int *perm, double *scale, double *Tfull, int n, hipStream_t s);
 
 // bit-order calibration (misc.hip): node codes of the calibration walks, and all_opt from internal to reference pattern order
-struct BitOrder { uint8_t gbit[40]; };                  // group k of the reference sits on bit gbit[k] of the internal pattern
 int        walk_flipped_bit(int chain, int step, int kbits, int seg_len, int nseg);
 hipError_t launch_walk_codes(const uint64_t *mask, int n, int kbits, int chains, int L, int seg_len, int nseg, int8_t *codes, hipStream_t s);
 hipError_t launch_pattern_gather(const double *in, int64_t npat, int kbits, const BitOrder &order, double *out, hipStream_t s);

@@ -52,6 +52,7 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    int coop_fault = 0;          // PARTLS_COOP_FAULT (tests): make the cooperative kernel's grid barrier time out (see SweepParams)
     bool no_tab_refine = false;  // PARTLS_NO_TAB_REFINE: refinement by host Cholesky even when the node solve left its tableau (A/B tests)
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
@@ -103,6 +104,7 @@ struct partls_ctx {
     double tol = 0.0;
     unsigned long long last_pivots = 0, last_vetoes = 0, last_blocks = 0;
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
+    bool coop_fallback = false;                    // the cooperative attempt of the current solve timed out at its grid barrier
     // final tableau of the last single-node solve on the register kernel (pinned host copies; see solve_nodes `want_tab`)
     double *hTab = nullptr;
     int8_t *hBasic = nullptr;

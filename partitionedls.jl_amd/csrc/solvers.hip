@@ -111,7 +111,9 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
         std::fill(suma.begin(), suma.end(), 0.0);
         for (int m = 0; m < Mp; ++m) for (int k : groups_of[(size_t)m]) suma[(size_t)k] += a[(size_t)m];          // sumα
         for (int m = 0; m < Mp; ++m) for (int k : groups_of[(size_t)m]) poa[(size_t)m] += suma[(size_t)k];        // Po * sumα'
-        for (int m = 0; m < Mp; ++m) a[(size_t)m] /= poa[(size_t)m];                 // a feature in no group: 0/0 = NaN, as in the reference
+        // a feature that belongs to no group has multiplier 0 in every alpha-step and P row 0 in predict: its alpha is irrelevant.  The
+        // reference divides 0 / 0 there (Alt.jl:98) and carries the NaN through every later iterate; here it stays 0
+        for (int m = 0; m < Mp; ++m) a[(size_t)m] = groups_of[(size_t)m].empty() ? 0.0 : a[(size_t)m] / poa[(size_t)m];
         for (int k = 0; k < Kp; ++k) b[(size_t)k] *= suma[(size_t)k];
         // ---- β-step: (A' G A) β = A' c,  A = Po∘α  (Alt.jl:109-110 in Gram form); the system is assembled on the device ---------
         std::vector<double> Hg((size_t)Kp * (Kp + 1)), H((size_t)Kp * Kp), g((size_t)Kp);

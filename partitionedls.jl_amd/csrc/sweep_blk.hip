@@ -111,6 +111,7 @@ struct LdsImage {
     int s_veto[2];                             // first vetoed step of a block (by block parity)
     // per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
     double s_best[2];                          // running minimum: obj^2, pattern (as bits)
+    unsigned char s_rbit[64];                  // reference bit of internal pattern bit b (exact ties only)
     unsigned long long s_vmask[16 * MAXT];     // group mask of variable v
     double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
 };
@@ -263,6 +264,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     if (tid < 2) s_veto[tid] = NO_VETO;
     if (tid == 0) { s_best[0] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[1] = -1; }
     if (tid < 16 * T) s_vmask[tid] = tid < p.n ? p.mask[tid] : 0ULL;
+    if (tid < 64) lds_image.s_rbit[tid] = tid < 40 ? p.rbit.gbit[tid] : 0;
     __syncthreads();
 
     double S[L::CNT];
@@ -497,7 +499,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             if (tid == THREADS - 1) {                                // lexicographic (objective, pattern) minimum: argmin's first-index rule
                 const double bo = s_best[0];
                 const long long bp = reinterpret_cast<long long *>(s_best)[1];
-                if (obj2 < bo || (obj2 == bo && (long long)pat < bp)) { s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat; }
+                if (obj2 < bo || (obj2 == bo && ref_index_less(pat, (unsigned long long)bp, lds_image.s_rbit))) { s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat; }
             }
         }
         if constexpr (NODE) {

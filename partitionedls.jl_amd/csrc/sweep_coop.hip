@@ -23,15 +23,21 @@
 // under rocprofv3, crashed the process inside exit() after the tool had finalised (round-1 finding, reproduced in round 2 with
 // every context closed and every buffer freed: profiles/README.md).  What the cooperative launch guaranteed — that all
 // workgroups are resident at once, so that nobody spins on a workgroup that cannot start — is ensured by the host instead:
-// the grid is capped at (compute units) x (resident workgroups per CU from the occupancy query), far above the <= 64 used.
+// the grid is capped at (compute units) x (resident workgroups per CU from the occupancy query), far above the <= 128 used.
+// The query cannot see other work on the device: a barrier that is not completed within 2 s of wall clock aborts the kernel and
+// the host repeats the solve on the one-workgroup kernel (see grid_barrier).
 #include "gj_panel.h"
 
 namespace partls {
 
 // All threads of all workgroups call it the same number of times.  `epoch` counts arrivals expected so far (this workgroup's
-// private copy); the counter is zeroed by the host before the launch and never reset inside the kernel.  The spin is bounded
-// (cdna_hip_programming.md §1): a workgroup that waits ~4 s gives up, returns false to all its threads, and the kernel exits
-// with n_unconverged poisoned so that the host reports an error instead of hanging the device.
+// private copy); ctr[0] is the arrival counter, ctr[1] the abort word; both are zeroed by the host before the launch and never
+// reset inside the kernel.  The spin is bounded by WALL CLOCK (cdna_hip_programming.md §1): s_memrealtime runs at a constant
+// 100 MHz, a workgroup that has waited 2 s gives up, raises the abort word — every other workgroup, resident now or scheduled
+// later, then leaves at its next poll instead of serving its own 2 s — and the kernel exits with n_unconverged poisoned.  That
+// can only happen when some workgroups of the grid are not resident (another process or context filled the CUs the occupancy
+// query counted as free): the host then repeats the solve on the one-workgroup kernel (solve_nodes, api.hip).
+static constexpr unsigned long long GRID_BARRIER_TIMEOUT_TICKS = 200000000ull;   // 2 s of s_memrealtime
 __device__ __forceinline__ bool grid_barrier(unsigned *ctr, unsigned nwg, unsigned &epoch, int *s_ok)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every wave's stores have left the wave ...
@@ -45,9 +51,19 @@ __device__ __forceinline__ bool grid_barrier(unsigned *ctr, unsigned nwg, unsign
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the compiler may drop the wait behind the write-back (ROCm 7.2)
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 27)) { *s_ok = 0; break; }
+            if ((++spins & 1023u) == 0) {                          // every ~1000 polls: the abort word and the clock
+                if (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { *s_ok = 0; break; }
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > GRID_BARRIER_TIMEOUT_TICKS) {
+                    __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *s_ok = 0;
+                    break;
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");         // drops this CU's stale L1 lines (and the other XCDs' lines in L2)
     }
@@ -81,6 +97,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
 
     double *Timg[2] = {p.scratch, p.scratch + (size_t)ld * ld};    // two tableau images (ping-pong, see the file header)
     const int nwg = gridDim.x, wg = blockIdx.x;
+    const unsigned nexp = (unsigned)(nwg + p.coop_fault);           // arrivals a barrier waits for (coop_fault: test hook, see SweepParams)
     const int rows_per = (ld + nwg - 1) / nwg;
     const int row0 = wg * rows_per, row1 = (row0 + rows_per < ld) ? row0 + rows_per : ld;
     const int nwords = (n + 63) >> 6;
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
         cur = flagbuf[n] & 1;
     }
     const int8_t *code = p.node_code;                              // one node: per-variable constraint codes
-    if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
+    if (!grid_barrier(p.grid_ctr, nexp, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
 
     unsigned long long npiv = 0, nunconv = 0, nblk = 0;
     int ninf_best = n + 1, patience = 3, rounds = 0;
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(COOP_THREADS) void sweep_coop_kernel(SweepParams p,
             ++nblk;
             cur ^= 1;
             // the other image is complete before anybody reads it (agent-scope release / acquire inside: per-XCD L2s are not coherent)
-            if (!grid_barrier(p.grid_ctr, (unsigned)nwg, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
+            if (!grid_barrier(p.grid_ctr, nexp, epoch, &s_ok)) { if (tid == 0 && p.n_unconverged) atomicAdd(p.n_unconverged, 1ULL << 40); return; }
         }
     }
     if (wg == 0) {

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
             const double obj2 = T[(size_t)n * ld + n];
             const double obj = sqrt(obj2 > 0.0 ? obj2 : 0.0);
             if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
-            if (obj < best_obj || (obj == best_obj && (long long)pat < best_pat)) { best_obj = obj; best_pat = (long long)pat; }
+            if (obj < best_obj || (obj == best_obj && best_pat >= 0 && ref_index_less(pat, (unsigned long long)best_pat, p.rbit.gbit))) { best_obj = obj; best_pat = (long long)pat; }
             if (p.node_piv && code && tid == 0) {                  // [pivots, blocks, scans] so far; this kernel reports pivots only
                 unsigned *o = p.node_piv + 3 * ((size_t)chain * p.chain_len + (size_t)(g - g0));
                 o[0] = (unsigned)npiv; o[1] = 0; o[2] = 0;

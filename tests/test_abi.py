@@ -72,3 +72,14 @@ def test_no_gpu_means_loud_failure_not_fallback(partls):
     with pytest.raises(partls.PartlsError) as ei:
         partls.fit(partls.Opt, X, y, P)
     assert ei.value.status == partls.lowlevel.ERR_NO_DEVICE
+
+
+def test_multi_device_entry_without_gpu(partls):
+    """partls_multi_create is part of the same contract: no device => PARTLS_ERR_NO_DEVICE, and RCCL is not loaded for it"""
+    lib = partls.lowlevel.lib()
+    if lib.partls_device_count() > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    assert lib.partls_multi_create(None, 0, C.byref(h)) == partls.lowlevel.ERR_NO_DEVICE and not h
+    assert lib.partls_multi_size(None) == 0 and lib.partls_multi_uses_rccl(None) == 0
+    assert "librccl" not in open("/proc/self/maps").read()

@@ -218,3 +218,64 @@ def test_bench_two_rank_control_flow_on_one_device(partls):
     assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
     assert j1["result"]["best_index"] == j2["result"]["best_index"]
     assert abs(j1["result"]["opt"] - j2["result"]["opt"]) <= 1e-12 * j1["result"]["opt"]
+
+
+def _alt_problem_n513(oracle, seed):
+    """D = 512 features -> n = 513 tableau variables: every alpha-step runs on the multi-workgroup (grid barrier) kernel"""
+    N, D, K = 1500, 512, 8
+    X, y, P, _ = oracle.synth(seed, N, D, K)
+    rng = np.random.default_rng(seed)
+    return X, y, P, rng.random(D + 1), (rng.random(K + 1) - 0.5) * 10
+
+
+def test_two_contexts_run_the_grid_barrier_kernel_concurrently(partls, oracle):
+    """Two contexts on two host threads run Alt at n = 513 at the same time: two grids with hand-written grid barriers share the
+    device.  Both must finish with the oracle's result (a barrier that cannot complete times out after 2 s of wall clock and the
+    solve is repeated on the one-workgroup kernel) — never a hang."""
+    import threading
+    probs = [_alt_problem_n513(oracle, 20260041 + i) for i in range(2)]
+    refs = [oracle.fit_alt(X, y, P, a0, b0, T=6) for X, y, P, a0, b0 in probs]
+    ctxs = [partls.Context(0) for _ in probs]
+    out = [None, None]
+
+    def run(i):
+        X, y, P, a0, b0 = probs[i]
+        try:
+            for _ in range(3):                                            # several fits each, so that the launches really interleave
+                ctxs[i].opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+                out[i] = ctxs[i].alt_prepared(a0, b0, eps=1e-6, T=6)
+        except Exception as e:                                            # noqa: BLE001
+            out[i] = e
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a grid-barrier kernel hung"
+    for i in range(2):
+        assert not isinstance(out[i], Exception), out[i]
+        a, b, t, opt, iters = out[i]
+        assert abs(opt - refs[i]["opt"]) <= 1e-8 * max(1.0, refs[i]["opt"])
+        np.testing.assert_allclose(a, refs[i]["alpha"], atol=1e-6)
+    for c in ctxs:
+        c.close()
+
+
+def test_grid_barrier_timeout_falls_back_to_one_workgroup(partls, oracle, monkeypatch):
+    """PARTLS_COOP_FAULT makes every grid barrier of the cooperative kernel wait for one arrival too many, i.e. behave as if part of
+    the grid were not resident: the kernel must abort within its 2 s wall-clock bound (abort word: all workgroups leave together)
+    and the solve must be repeated on the one-workgroup kernel with the right answer."""
+    import time
+    X, y, P, a0, b0 = _alt_problem_n513(oracle, 20260043)
+    ref = oracle.fit_alt(X, y, P, a0, b0, T=2)
+    monkeypatch.setenv("PARTLS_COOP_FAULT", "1")
+    ctx = partls.Context(0)
+    ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    t0 = time.perf_counter()
+    a, b, t, opt, iters = ctx.alt_prepared(a0, b0, eps=1e-6, T=2)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    assert abs(opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(a, ref["alpha"], atol=1e-6)
+    assert 2.0 * iters <= dt < 4.0 * iters + 5.0, dt                      # one ~2 s timeout per alpha-step, not one per workgroup

@@ -272,3 +272,78 @@ def test_calibrated_order_on_the_global_memory_kernel(partls, oracle, monkeypatc
     assert unconv == 0 and bi == ref["best_index"]
     np.testing.assert_allclose(allo, ref["all_opt"], rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(opt, ref["opt"], rtol=1e-9)
+
+
+def test_tie_between_null_column_groups_keeps_the_first_reference_index(partls, oracle, monkeypatch):
+    """Two groups that own only all-zero feature columns (non-empty groups, Opt.jl:28-29 gives them +-0 columns): their four sign
+    combinations are the same subproblem, the sweep sees bitwise ties INSIDE a workgroup's chain (the calibration puts both groups
+    on the two fastest Gray bits, in an order of its own), and both the raw sweep winner — what dist.allreduce_argmin receives —
+    and fit's best_index must be the reference's first index (argmin, Opt.jl:96) in either visiting order."""
+    X, y, P, _ = _order_problem(seed=21, K=7)
+    K = P.shape[1]
+    X = np.asfortranarray(np.hstack([X, np.zeros((X.shape[0], 3))]))
+    P2 = np.zeros((X.shape[1], K + 2), dtype=np.int64)
+    # the two null groups get the reference bits 1 and K+1; the real groups keep their relative order around them
+    cols = [0, 2, 3, 4, 5, 6, 7]
+    assert K == len(cols)
+    P2[:P.shape[0], cols] = P
+    P2[P.shape[0], 1] = 1; P2[P.shape[0] + 1, 1] = 1; P2[P.shape[0] + 2, K + 1] = 1
+    ref = oracle.fit_opt(X, y, P2, 0.0, return_all=True)
+    nullmask = (1 << 1) | (1 << (K + 1))
+    assert ref["best_index"] & nullmask == 0
+    for mode in ("identity", "calibrate"):
+        ctx = _ctx_with_order(partls, monkeypatch, mode)
+        ctx.opt_prepare(X, y, P2, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+        gbit, cost = ctx.bit_order()
+        if mode == "calibrate":
+            assert cost[1] == 0.0 and cost[K + 1] == 0.0 and sorted([gbit[1], gbit[K + 1]]) == [0, 1]
+        bo, bp, allo, unconv = ctx.opt_sweep(0, -1, want_all=True)
+        assert unconv == 0
+        assert bp == int(np.argmin(allo)), (mode, bp, int(np.argmin(allo)))      # first index among the bitwise-equal minima
+        assert bp & nullmask == 0
+        # shards whose boundaries cut through the tie set: members of the set that sit in different shards are reached along different
+        # chain paths, so their tracked objectives agree to round-off only and any of them may win the reduce — finish() then clears
+        # the bits of the null groups, which is what makes best_index the reference's
+        parts = [ctx.opt_sweep(*partls.dist.shard_range(ctx.num_patterns(), r, 5)) for r in range(5)]
+        bps = min((p[0], p[1]) for p in parts)[1]
+        assert bps & ~nullmask == bp
+        assert ctx.opt_finish(bps)[4] == ref["best_index"]
+        a, b, t, opt, bi = ctx.opt_finish(bp)
+        ctx.close()
+        assert bi == ref["best_index"], (mode, bi, ref["best_index"])
+        np.testing.assert_allclose(allo, ref["all_opt"], rtol=1e-8, atol=1e-9)
+    # free-intercept mode through fit(): the null groups' bits stay clear as well
+    m, _, rep = partls.fit(partls.Opt, X, y, P2)
+    assert rep.best_index == ref["best_index"]
+
+
+def test_solutions_survive_a_later_fit(partls):
+    """returnAllSolutions (Opt.jl:99-101): the returned (opt_b, model_b) list stays valid after other fits have used the shared
+    context, as in the reference — the models are rebuilt on a private context once the shared one has moved on."""
+    g = load_golden("toy")
+    model, _, rep = partls.fit(partls.Opt, g["X"], g["y"], g["P"], returnAllSolutions=True)
+    sols = rep.solutions
+    first = sols[3]
+    rng = np.random.default_rng(0)
+    X2 = rng.standard_normal((50, 5)); y2 = rng.standard_normal(50); P2 = np.eye(5, dtype=np.int64)[:, :2]; P2[2:, 1] = 1
+    partls.fit(partls.Opt, X2, y2, P2)                                   # takes the shared context over
+    for b in range(8):
+        o, m = sols[b]
+        np.testing.assert_allclose(m.α, g["opt_all_alpha"][b], atol=1e-9)
+        np.testing.assert_allclose(m.β, g["opt_all_beta"][b], atol=1e-9)
+    np.testing.assert_array_equal(sols[3][1].α, first[1].α)
+
+
+def test_alt_feature_in_no_group_is_ignored_not_nan(partls, oracle):
+    """A feature whose row of P is zero never enters the model (predict multiplies it by 0).  Alt.jl:98 divides 0 / 0 for it; here
+    its alpha stays 0 and the fit equals the fit without that column."""
+    rng = np.random.default_rng(4)
+    N, M, K = 300, 7, 3
+    X = rng.standard_normal((N, M)); y = X[:, :6] @ rng.standard_normal(6) + 0.3 + 0.1 * rng.standard_normal(N)
+    P = np.zeros((M, K), dtype=np.int64); P[[0, 1], 0] = 1; P[[2, 3], 1] = 1; P[[4, 5], 2] = 1       # feature 6: no group
+    a0 = rng.random(M + 1); b0 = (rng.random(K + 1) - 0.5) * 10
+    m, _, rep = partls.fit(partls.Alt, X, y, P, alpha0=a0, beta0=b0, T=50)
+    assert np.all(np.isfinite(m.α)) and np.all(np.isfinite(m.β)) and np.isfinite(rep.opt) and m.α[6] == 0.0
+    ref = oracle.fit_alt(X[:, :6], y, P[:6], np.delete(a0, 6), b0, T=50)
+    assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(m.α[:6], ref["alpha"], atol=1e-7)
