@@ -34,7 +34,10 @@ typedef enum {
     PARTLS_ERR_HIP = 5,            /* a HIP runtime call failed (message has the hipError string)         */
     PARTLS_ERR_NOT_CONVERGED = 6,  /* an active-set solve hit its pivot cap                               */
     PARTLS_ERR_UNSUPPORTED = 7,    /* shape outside what the kernels are built for                        */
-    PARTLS_ERR_STATE = 8           /* staged calls issued out of order                                    */
+    PARTLS_ERR_STATE = 8,          /* staged calls issued out of order                                    */
+    PARTLS_ERR_ILL_CONDITIONED = 9 /* the model's KKT conditions fail when checked against the DATA: X is too ill-conditioned for the
+                                      fp64 Gram form (cond(X)^2 * eps >~ 1).  Outputs are filled with the best Gram-form model;
+                                      a QR-based solver (the reference's, Opt.jl:89) is the right tool for this input          */
 } partls_status;
 
 /* flags for the Opt entry points */
@@ -183,6 +186,11 @@ partls_status partls_get_pivots(const partls_ctx *ctx, int64_t *pivots);
 /* entering pivots the last partls_opt_sweep refused under the leave-one-out dependence rule (0 on well-conditioned data; a
  * large count says the data are rank deficient on the unit-diagonal scale — see DESIGN.md §4, numerical notes) */
 partls_status partls_get_vetoes(const partls_ctx *ctx, int64_t *vetoes);
+/* data-space KKT violation of the model the last partls_opt_finish / partls_bnb_leaf (hence fit(Opt), fit(BnB)) returned: the largest
+ * of |x_m'r| (passive or free variable), f_m x_m'r (variable at its bound) and -f_m w_m / max|w| over every variable, r = yo - Xo w
+ * computed from the data, in units of ||x_m|| ||y||.  ~1e-13 on well-conditioned data; above 1e-8 (PARTLS_KKT_TOL) the call
+ * returns PARTLS_ERR_ILL_CONDITIONED (see there). */
+partls_status partls_get_kkt_violation(const partls_ctx *ctx, double *violation);
 /* debugging / tests: copy the Gram products of the prepared problem to the host: G ((M+2) x (M+2), column-major,
  * variables ordered [features, intercept, y]), i.e. G, c = G[:, M+1], yy = G[M+1, M+1], after η has been applied. */
 partls_status partls_get_gram(const partls_ctx *ctx, double *G_aug);

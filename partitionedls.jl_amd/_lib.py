@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("PARTLS_LIB") or os.path.join(_HERE, "libpartls_hip.so")   # PARTLS_LIB: diagnostic builds only
 CSRC = os.path.join(_HERE, "csrc")
 
-OK, ERR_BAD_ARG, ERR_BAD_PARTITION, ERR_NONFINITE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED, ERR_STATE = range(9)
+OK, ERR_BAD_ARG, ERR_BAD_PARTITION, ERR_NONFINITE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED, ERR_STATE, ERR_ILL_CONDITIONED = range(10)
 OPT_FAITHFUL_INTERCEPT = 1
 OPT_GENERIC_KERNEL = 2
 T_GRAM, T_PREP, T_SWEEP, T_FINISH, T_CALIB = range(5)
@@ -57,6 +57,7 @@ SYMBOLS = [
     ("partls_get_gram", C.c_int, [C.c_void_p, _dp]),
     ("partls_get_pivots", C.c_int, [C.c_void_p, _ip]),
     ("partls_get_vetoes", C.c_int, [C.c_void_p, _ip]),
+    ("partls_get_kkt_violation", C.c_int, [C.c_void_p, _dp]),
 ]
 
 _lib = None

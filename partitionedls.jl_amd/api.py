@@ -208,6 +208,12 @@ class Context:
         _check(L.lib().partls_get_vetoes(self._h, C.byref(n)))
         return n.value
 
+    def kkt_violation(self):
+        """data-space KKT violation of the last finished winner (include/partls.h: partls_get_kkt_violation)"""
+        v = C.c_double()
+        _check(L.lib().partls_get_kkt_violation(self._h, C.byref(v)))
+        return v.value
+
     def gram(self):
         N, M, K = self._shape
         G = np.zeros((M + 2, M + 2), order="F")

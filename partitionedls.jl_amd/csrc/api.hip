@@ -77,6 +77,8 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (!y) { set_error("y is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
     c->prepared = false;
+    c->near_for = -1; c->near_pat.clear();
+    c->sweep_vetoes = 0;
     c->coop_state_valid = false;
     c->order_ready = false; c->order_identity = true; c->flip_cost.clear(); c->ms[PARTLS_T_CALIB] = 0.0;
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
@@ -308,29 +310,96 @@ void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double
     }
 }
 
-partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt)
+partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt, std::vector<double> *grad)
 {
-    const int64_t M = c->M;
+    const int64_t M = c->M, N = c->N;
     const int nb = 1024;
     PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
     PARTLS_HIP_CHECK(c->partial.ensure(nb * sizeof(double)));
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    PARTLS_HIP_CHECK(launch_residual(c->dX, c->N, M, c->ldX, c->dy, c->wdev.as<double>(), w[(size_t)M],
-                                     c->partial.as<double>(), nb, nullptr, c->stream));
+    double *yhat = nullptr;
+    const int xr = xtr_slices(N);
+    std::vector<double> gpart;
+    if (grad) {                                          // the same pass leaves Xo w; a second one gives Xo'(y - Xo w)
+        PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
+        PARTLS_HIP_CHECK(c->gD.ensure((size_t)xr * (M + 1) * sizeof(double)));
+        yhat = c->yhatD.as<double>();
+        gpart.resize((size_t)xr * (M + 1));
+    }
+    PARTLS_HIP_CHECK(launch_residual(c->dX, N, M, c->ldX, c->dy, c->wdev.as<double>(), w[(size_t)M],
+                                     c->partial.as<double>(), nb, yhat, c->stream));
+    if (grad) {
+        PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, yhat, c->gD.as<double>(), c->stream));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(gpart.data(), c->gD.p, gpart.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
     std::vector<double> part((size_t)nb);
     PARTLS_HIP_CHECK(hipMemcpyAsync(part.data(), c->partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     double s = 0.0;
     for (int b = 0; b < nb; ++b) s += part[(size_t)b];
+    if (grad) {
+        grad->assign((size_t)M + 1, 0.0);
+        for (int64_t m = 0; m <= M; ++m) {
+            double sg = 0.0;
+            for (int r = 0; r < xr; ++r) sg += gpart[(size_t)r * (M + 1) + m];
+            (*grad)[(size_t)m] = sg;
+        }
+    }
     if (c->eta != 0.0) {
         for (int64_t k = 0; k <= c->K; ++k) {           // the K' regularisation rows: sqrt(eta) * sum_{m in group k} w_m
             double g = 0.0;
             for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) g += w[(size_t)m];
             s += c->eta * g * g;
+            if (grad) for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) (*grad)[(size_t)m] -= c->eta * g;
         }
     }
     *opt = std::sqrt(s);
     return PARTLS_OK;
+}
+
+// KKT conditions of ONE sign-constrained subproblem in DATA space (no Gram entry involved besides the column norms that scale the
+// test): g = Xo'(yo - Xo w) is minus the gradient, so at the optimum of  min ||Xo w - yo||  s.t.  f_m w_m >= 0
+//     w_m != 0 or m free :  g_m = 0                (stationarity on the passive set)
+//     w_m == 0, f_m != 0 :  f_m g_m <= 0           (no descent direction inside the orthant)
+//     f_m w_m >= 0.
+// Returns the largest violation in units of ||x_m|| ||y||, i.e. comparable with the sweep's own tolerance (1e-11 on the
+// unit-diagonal scale).  What it catches that the tableau cannot: a column the leave-one-out rule rejected as dependent although it
+// carries information below the resolution of the fp64 Gram (cond(X~) >~ 1e6) — the reference's QR-based NNLS (Opt.jl:89) takes it.
+// `code[m]`: +1 / -1 / 0 (forced to zero) / 2 (free) for m in [features, intercept].
+// When is a data-space KKT violation evidence that the Gram form has lost the problem?  A violation above kkt_tol (1e-8) always is.  Below
+// that, a well-conditioned optimum can legitimately sit at up to the sweep's own tolerance (1e-11: a variable at its bound whose gradient
+// is +5e-12 is not worth a pivot); but when the winner's basis is ill-conditioned (a leave-one-out pivot below 1e-9 on the unit-diagonal
+// scale, i.e. cond(X~_B) >~ 3e4, or columns were refused as dependent) a residual gradient of 1e-12 along a nearly dependent column is worth
+// g^2 / d = 1e-24 / 1e-13 — the difference between the reference's model and this one.  Measured (tools/illcond_check.py, cond 7e2 .. 7e7):
+// every fit that equals the oracle's has a violation <= 3e-15, every one that differs >= 4e-12.
+bool kkt_says_ill_conditioned(const partls_ctx *c)
+{
+    if (c->last_kkt > c->knobs.kkt_tol) return true;
+    const bool suspicious = c->last_min_loo < 1e-9 || c->sweep_vetoes > 0;
+    return suspicious && c->last_kkt > c->knobs.kkt_tol_tight;
+}
+
+double kkt_violation_data(const partls_ctx *c, const std::vector<double> &w, const std::vector<double> &g, const std::vector<int8_t> &code,
+                          int *worst)
+{
+    const int M = (int)c->M;
+    const double yy = h_reg(c, M + 1, M + 1);
+    const double ynorm = std::sqrt(yy > 0.0 ? yy : 0.0);
+    double worstv = 0.0, wmax = 0.0;
+    for (int m = 0; m <= M; ++m) wmax = std::max(wmax, std::fabs(w[(size_t)m]));
+    if (worst) *worst = -1;
+    for (int m = 0; m <= M; ++m) {
+        const double d = h_reg(c, m, m);
+        if (!(d > 0.0) || !(d > 1e-14 * std::fabs(c->hG[(size_t)m * c->ldg + m]))) continue;   // null column: never in any basis
+        const double gs = g[(size_t)m] / (std::sqrt(d) * (ynorm > 0.0 ? ynorm : 1.0));
+        const int f = code[(size_t)m];
+        double v = 0.0;
+        if (f == 2 || w[(size_t)m] != 0.0) v = std::fabs(gs);
+        else if (f != 0) v = std::max(0.0, (double)f * gs);
+        if (f == 1 || f == -1) v = std::max(v, wmax > 0.0 ? std::max(0.0, -(double)f * w[(size_t)m] / wmax) : 0.0);
+        if (v > worstv) { worstv = v; if (worst) *worst = m; }
+    }
+    return worstv;
 }
 
 partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps)
@@ -346,6 +415,19 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     // Schur complement): delta_B = -D T_BB D rhs is one p x p matrix-vector product per step instead of a p^3/6 factorisation.
     // Valid when the basis IS the support (a basic variable that came out exactly 0 would not be in `sup`): otherwise Cholesky.
     std::vector<int> tabsup;                             // tableau indices of the support, when the tableau path applies
+    // conditioning of the basis the node solve ended on, while its tableau is at hand: the diagonal of the basic block is -1 / (leave-one-out
+    // pivot of that variable), so the smallest leave-one-out pivot is a lower bound of 1 / cond(G~_BB)  (0 = unknown: no tableau)
+    c->last_min_loo = 0.0;
+    if (c->tab_valid) {
+        double tmax = 0.0;
+        for (int i = 0; i < c->n; ++i) {
+            if (!c->hBasic[i]) continue;
+            const int ti = i >> 4, a = i & 15;
+            const double d = c->tab_full ? c->hTab[(size_t)i * (c->n + 1) + i] : c->hTab[((size_t)(ti * (ti + 1) / 2 + ti)) * 256 + a + 16 * a];
+            tmax = std::max(tmax, std::fabs(d));
+        }
+        c->last_min_loo = tmax > 0.0 ? 1.0 / tmax : 1.0;
+    }
     bool use_tab = c->tab_valid && free_intercept == !c->faithful && !c->knobs.no_tab_refine;
     c->tab_valid = false;                                // one use: the next node solve overwrites the buffers
     if (use_tab) {
@@ -555,6 +637,8 @@ partls_status partls_create(int device, partls_ctx **out)
     if (const char *e = getenv("PARTLS_GRAM_CR")) c->knobs.gram_cr = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_ROWS")) c->knobs.coop_rows = atoi(e);
     if (const char *e = getenv("PARTLS_BIT_ORDER")) c->knobs.bit_order = !strcmp(e, "identity") ? 1 : (!strcmp(e, "calibrate") ? 2 : 0);
+    if (const char *e = getenv("PARTLS_KKT_TOL")) c->knobs.kkt_tol = atof(e);
+    if (const char *e = getenv("PARTLS_KKT_TOL_TIGHT")) c->knobs.kkt_tol_tight = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
@@ -771,9 +855,10 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     int grid = (int)std::min<int64_t>(nchains, c->knobs.grid > 0 ? c->knobs.grid : (c->use_reg ? 4096 : 1024));
     if (grid < 1) grid = 1;
 
-    // one output block on the device, one copy back: [counters (4 x 8 B) | best objective (grid) | best pattern (grid)]
-    const size_t sweep_words = 4 + 2 * (size_t)grid;
-    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 2 * (size_t)std::max(grid, 4096))));
+    // one output block on the device, one copy back: [counters (4 x 8 B) | best objective (grid) | best pattern (grid) | runner-up
+    // objective (grid) | runner-up pattern (grid)]
+    const size_t sweep_words = 4 + 4 * (size_t)grid;
+    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 4 * (size_t)std::max(grid, 4096))));
     PARTLS_HIP_CHECK(hipMemsetAsync(c->bestObj.p, 0, 4 * sizeof(unsigned long long), c->stream));
     if (all_opt) {
         PARTLS_HIP_CHECK(c->allOpt.ensure((size_t)npat * sizeof(double)));
@@ -790,6 +875,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
     p.all_opt = all_opt ? c->allOpt.as<double>() : nullptr;
     p.best_obj = c->bestObj.as<double>() + 4; p.best_pat = reinterpret_cast<int64_t *>(c->bestObj.as<double>() + 4 + grid);
+    p.second_obj = c->bestObj.as<double>() + 4 + 2 * (size_t)grid; p.second_pat = reinterpret_cast<int64_t *>(c->bestObj.as<double>() + 4 + 3 * (size_t)grid);
     p.n_unconverged = c->bestObj.as<unsigned long long>();
     p.n_pivots = c->bestObj.as<unsigned long long>() + 1;
     p.n_vetoes = c->bestObj.as<unsigned long long>() + 2;
@@ -822,6 +908,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     std::memcpy(bp.data(), sweep_out.data() + 4 + grid, (size_t)grid * sizeof(int64_t));
     c->last_pivots = cnt[1];
     c->last_vetoes = cnt[2];
+    c->sweep_vetoes = cnt[2];
     if (c->knobs.print_stamps) {                         // diagnostic build (-DPARTLS_STAMPS): phase shares of workgroup 0
         double st[32] = {0};
         if (hipMemcpy(st, c->scratch.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
@@ -838,6 +925,25 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
         bp[(size_t)i] = reference_pattern(c, bp[(size_t)i]);
         if (bpat < 0 || bo[(size_t)i] < bobj || (bo[(size_t)i] == bobj && bp[(size_t)i] < bpat)) { bobj = bo[(size_t)i]; bpat = bp[(size_t)i]; }
     }
+    // Near ties.  The tracked objective^2 carries the Gram form's absolute error (~eps * y'y times the pivots of the chain), so two
+    // patterns closer than that can come out in the wrong order relative to the reference, which computes every objective from the
+    // data (Opt.jl:90).  Candidates within that error of the winner — each workgroup reports its minimum and its runner-up — are
+    // remembered (at most 3, best first); partls_opt_finish re-ranks them with the objective from the data.
+    c->near_pat.clear();
+    c->near_for = bpat;
+    if (bpat >= 0) {
+        const double yy = h_reg(c, (int)c->M + 1, (int)c->M + 1);
+        const double lim2 = bobj * bobj + 1e-13 * (yy > 0.0 ? yy : 0.0);
+        std::vector<std::pair<double, int64_t>> cand;
+        const double *so = sweep_out.data() + 4 + 2 * (size_t)grid;
+        const int64_t *sp = reinterpret_cast<const int64_t *>(sweep_out.data() + 4 + 3 * (size_t)grid);
+        for (int i = 0; i < grid; ++i) {
+            if (bp[(size_t)i] >= 0 && bp[(size_t)i] != bpat && bo[(size_t)i] * bo[(size_t)i] <= lim2) cand.emplace_back(bo[(size_t)i], bp[(size_t)i]);
+            if (sp[i] >= 0 && so[i] * so[i] <= lim2) { const int64_t r = reference_pattern(c, sp[i]); if (r != bpat) cand.emplace_back(so[i], r); }
+        }
+        std::sort(cand.begin(), cand.end());
+        for (size_t i = 0; i < cand.size() && c->near_pat.size() < 3; ++i) c->near_pat.push_back(cand[i].second);
+    }
     if (best_obj) *best_obj = bobj;
     if (best_pattern) *best_pattern = bpat;
     if (n_unconverged) *n_unconverged = (int64_t)cnt[0];
@@ -852,41 +958,77 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     if (pattern < 0 || pattern >= ((int64_t)1 << (c->K + 1))) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     const uint64_t kmask = ((uint64_t)1 << c->kbits) - 1;
-    std::vector<double> sols, obj2, w;
-    unsigned long long unconv = 0;
-    t_begin(c, PARTLS_T_FINISH);
-    const auto f0 = std::chrono::steady_clock::now();
-    std::vector<int8_t> codes;
-    opt_codes(c, (uint64_t)pattern & kmask, codes);
-    partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
-    if (st != PARTLS_OK) return st;
-    const auto f1 = std::chrono::steady_clock::now();
-    unscale_solution(c, sols.data(), w);
-    st = refine_solution(c, w, !c->faithful);             // QR-level accuracy of the winner on ill-conditioned data
-    if (st != PARTLS_OK) return st;
-    const auto f2 = std::chrono::steady_clock::now();
-    uint64_t full = (uint64_t)pattern & kmask;
-    if (!c->faithful) { if (w[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
-    else full = (uint64_t)pattern;
     // A group without any feature leaves the subproblem unchanged: the reference then sees bitwise equal objectives for the two
     // patterns and argmin keeps the first, i.e. the one with that group's bit clear (Opt.jl:96)
     // — and so does a group whose every feature is a null column (scale 0: never in a basis; the reference's X .* f' has +-0 columns)
     uint64_t used = 1ULL << c->K;
     for (int i = 0; i < c->n; ++i) if (c->hScale[(size_t)i] != 0.0) used |= c->mask_tab[(size_t)i];
+
+    // candidates: the given pattern and, when it is the winner of this context's last sweep, the near ties that sweep recorded —
+    // distinct subproblems only (patterns that differ in the bits of unused groups are the same subproblem)
+    std::vector<uint64_t> cands{(uint64_t)pattern & kmask & used};
+    if (pattern == c->near_for)
+        for (int64_t q : c->near_pat) {
+            const uint64_t v = (uint64_t)q & kmask & used;
+            if (std::find(cands.begin(), cands.end(), v) == cands.end()) cands.push_back(v);
+        }
+    c->near_for = -1;
+    c->near_pat.clear();
+
+    t_begin(c, PARTLS_T_FINISH);
+    const auto f0 = std::chrono::steady_clock::now();
+    std::vector<double> sols, obj2, w, wbest, g, gbest;
+    std::vector<int8_t> codes;
+    unsigned long long unconv = 0, unconv_best = 0;
+    double obest = INFINITY, loo_best = 0.0;
+    uint64_t pbest = cands[0];
+    for (size_t ci = 0; ci < cands.size(); ++ci) {
+        opt_codes(c, cands[ci], codes);
+        partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
+        if (st != PARTLS_OK) return st;
+        unscale_solution(c, sols.data(), w);
+        st = refine_solution(c, w, !c->faithful);         // QR-level accuracy of the winner on ill-conditioned data
+        if (st != PARTLS_OK) return st;
+        double o = 0.0;
+        st = data_objective(c, w, &o, &g);                // Opt.jl:90 from the data, and Xo'(yo - Xo w) for the KKT check below
+        if (st != PARTLS_OK) return st;
+        if (c->knobs.finish_trace && cands.size() > 1) fprintf(stderr, "[finish] near tie: pattern %llu data objective %.17g\n", (unsigned long long)cands[ci], o);
+        // argmin over the data objectives, first reference index on exact ties (Opt.jl:96)
+        if (ci == 0 || o < obest || (o == obest && cands[ci] < pbest)) { obest = o; pbest = cands[ci]; wbest = w; gbest = g; unconv_best = unconv; loo_best = c->last_min_loo; }
+    }
+    const auto f1 = std::chrono::steady_clock::now();
+    uint64_t full = pbest;
+    if (!c->faithful) { if (wbest[(size_t)c->M] > 0.0) full |= (1ULL << c->K); }     // first-index tie-break when t == 0
     full &= used;
-    st = data_objective(c, w, opt);
+    // data-space KKT conditions of the winner, every variable — including those the leave-one-out rule kept out of the basis
+    std::vector<int8_t> vcode((size_t)c->M + 1, 0);
+    for (int64_t m = 0; m <= c->M; ++m) {
+        if (m == c->M && !c->faithful) { vcode[(size_t)m] = 2; continue; }          // free intercept
+        const int f = 2 * __builtin_popcountll(c->mask_aug[(size_t)m] & full) - __builtin_popcountll(c->mask_aug[(size_t)m]);
+        vcode[(size_t)m] = (int8_t)((f > 0) - (f < 0));
+    }
+    int worst = -1;
+    c->last_kkt = kkt_violation_data(c, wbest, gbest, vcode, &worst);
+    *opt = obest;
     if (c->knobs.finish_trace) {
-        const auto f3 = std::chrono::steady_clock::now();
+        const auto f2 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[finish] node solve %.3f ms, refine %.3f ms, data objective %.3f ms\n", ms(f0, f1), ms(f1, f2), ms(f2, f3));
+        fprintf(stderr, "[finish] %zu candidate(s): solve + refine + data objective / gradient %.3f ms, KKT check %.3f ms; data-space KKT violation %.3e (variable %d)\n",
+                cands.size(), ms(f0, f1), ms(f1, f2), c->last_kkt, worst);
     }
     t_end(c, PARTLS_T_FINISH);
-    if (st != PARTLS_OK) return st;
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
-    cleanup_opt(c, w, full, alpha, beta, t);
+    cleanup_opt(c, wbest, full, alpha, beta, t);
     if (best_index) *best_index = (int64_t)full;
-    if (unconv) { set_error("winner re-solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    if (unconv_best) { set_error("winner re-solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    c->last_min_loo = loo_best;
+    if (kkt_says_ill_conditioned(c)) {
+        set_error("the winner's KKT conditions do not hold in data space (violation %.2e of ||x|| ||y|| at variable %d; smallest leave-one-out "
+                  "pivot of its basis %.1e, %llu columns refused as dependent in the sweep): X is too ill-conditioned for the fp64 Gram form "
+                  "(cond^2 * eps >~ 1e-4); the outputs hold the best Gram-form model", c->last_kkt, worst, c->last_min_loo, c->sweep_vetoes);
+        return PARTLS_ERR_ILL_CONDITIONED;
+    }
     return PARTLS_OK;
 }
 
@@ -1030,6 +1172,13 @@ partls_status partls_get_pivots(const partls_ctx *c, int64_t *pivots)
 {
     if (!c || !pivots) { set_error("partls_get_pivots: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *pivots = (int64_t)c->last_pivots;
+    return PARTLS_OK;
+}
+
+partls_status partls_get_kkt_violation(const partls_ctx *c, double *violation)
+{
+    if (!c || !violation) { set_error("partls_get_kkt_violation: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *violation = c->last_kkt;
     return PARTLS_OK;
 }
 

@@ -40,6 +40,8 @@ struct SweepParams {
     double *all_opt;             // optional [2^kbits] objective per pattern index
     double *best_obj;            // [gridDim.x] per-workgroup minimum objective
     int64_t *best_pat;           // [gridDim.x] its pattern index (internal bit order; ties broken on the REFERENCE index, see rbit)
+    double *second_obj;          // optional [gridDim.x]: the workgroup's runner-up (second smallest objective, a different pattern) and
+    int64_t *second_pat;         // its pattern, -1 if none: candidates of the host's near-tie re-rank by the data objective (api.hip)
     BitOrder rbit;               // chain mode: rbit.gbit[b] = the reference's bit (group) that internal pattern bit b carries.  Only
                                  // exact objective ties read it: argmin keeps the first REFERENCE index (Opt.jl:96)
     unsigned long long *n_unconverged;   // patterns that hit max_rounds

@@ -57,6 +57,9 @@ struct partls_knobs {
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
+    double kkt_tol_tight = 1e-13;// PARTLS_KKT_TOL_TIGHT: the same when the winner's basis is ill-conditioned (see kkt_says_ill_conditioned, api.hip)
+    double kkt_tol = 1e-8;       // PARTLS_KKT_TOL: data-space KKT violation of the winner (units of ||x_m|| ||y||) above which fit(Opt) / fit(BnB) report
+                                 // PARTLS_ERR_ILL_CONDITIONED instead of PARTLS_OK
     double cal_wb = 1.0, cal_ws = 1.0;  // PARTLS_CAL_WB / PARTLS_CAL_WS: multipliers of the block / scan weights of the bit-order cost model (experiments)
     int bit_order = 0;           // PARTLS_BIT_ORDER: 0 automatic (calibrate when the sweep is long enough to repay it), "identity" = 1
                                  // (group k on Gray bit k), "calibrate" = 2 (always measure; small problems in the tests)
@@ -103,6 +106,13 @@ struct partls_ctx {
     std::vector<double> flip_cost;                 // measured pivots per flip of group k (empty when not calibrated)
     double tol = 0.0;
     unsigned long long last_pivots = 0, last_vetoes = 0, last_blocks = 0;
+    // near ties of the last sweep (reference pattern indices whose tracked objective^2 lies within the Gram form's own error of the
+    // winner's): partls_opt_finish re-ranks them by the objective computed from the data before it fixes the winner
+    std::vector<int64_t> near_pat;
+    int64_t near_for = -1;
+    double last_kkt = 0.0;                         // data-space KKT violation of the last finished winner
+    double last_min_loo = 0.0;                     // smallest leave-one-out pivot of the basis of the last refined node solve (0: unknown)
+    unsigned long long sweep_vetoes = 0;           // leave-one-out refusals of the last sweep (node solves overwrite last_vetoes)
     bool coop_state_valid = false;                 // scratch holds the tableau/basis of the previous cooperative solve
     bool coop_fallback = false;                    // the cooperative attempt of the current solve timed out at its grid barrier
     // final tableau of the last single-node solve on the register kernel (pinned host copies; see solve_nodes `want_tab`)
@@ -133,7 +143,11 @@ void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes
 // scaled tableau solution -> w over [features, intercept] (length M+1); a free intercept is recovered from the Gram copy
 void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w);
 // ||Xo w - yo||_2 from the data (+ the eta rows): Opt.jl:90
-partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt);
+// grad (optional): Xo'(yo - Xo w) over [features, intercept], from the data (one more pass over X)
+partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt, std::vector<double> *grad = nullptr);
+bool kkt_says_ill_conditioned(const partls_ctx *c);
+double kkt_violation_data(const partls_ctx *c, const std::vector<double> &w, const std::vector<double> &g, const std::vector<int8_t> &code,
+                          int *worst);
 // Iterative refinement of a solution w (over [features, intercept]) on its own support, in data space: residual and
 // X'r on the device; the small SPD solve uses the inverse the pivoting left in the final tableau of the node solve (want_tab;
 // register kernel) or, without one, a Cholesky factorisation of the host Gram copy.  Brings a Gram-based solution (error ~ cond^2 eps) to the

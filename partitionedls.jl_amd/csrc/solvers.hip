@@ -255,9 +255,20 @@ partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, doubl
     }
     for (int64_t k = 0; k < K; ++k) beta[k] = bsum[(size_t)k];
     *t = bsum[(size_t)K];
-    st = data_objective(c, w, opt);
+    std::vector<double> g;
+    st = data_objective(c, w, opt, &g);
     if (st != PARTLS_OK) return st;
     if (unconv) { set_error("partls_bnb_leaf: the node solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    // the leaf's KKT conditions against the data, as partls_opt_finish checks its winner (api.hip: kkt_violation_data)
+    std::vector<int8_t> vcode((size_t)Mp, 0);
+    for (int v = 0; v < n; ++v) vcode[(size_t)c->perm[(size_t)v]] = codes[(size_t)v];
+    int worst = -1;
+    c->last_kkt = kkt_violation_data(c, w, g, vcode, &worst);
+    if (kkt_says_ill_conditioned(c)) {
+        set_error("partls_bnb_leaf: the model's KKT conditions do not hold in data space (violation %.2e at variable %d): X is too "
+                  "ill-conditioned for the fp64 Gram form", c->last_kkt, worst);
+        return PARTLS_ERR_ILL_CONDITIONED;
+    }
     return PARTLS_OK;
 }
 

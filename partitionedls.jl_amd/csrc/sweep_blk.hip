@@ -110,7 +110,7 @@ struct LdsImage {
     unsigned s_sum[16];                        // [2][8] per-wave summary of s_inf: count | tile bits << 8
     int s_veto[2];                             // first vetoed step of a block (by block parity)
     // per-thread state that is touched once per pattern lives in LDS, not in VGPRs (the register file holds the tableau):
-    double s_best[2];                          // running minimum: obj^2, pattern (as bits)
+    double s_best[4];                          // running minimum: obj^2, pattern (as bits); runner-up: obj^2, pattern
     unsigned char s_rbit[64];                  // reference bit of internal pattern bit b (exact ties only)
     unsigned long long s_vmask[16 * MAXT];     // group mask of variable v
     double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
@@ -262,7 +262,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     if (tid < MB + 64) Dinv[tid] = 0.0;
     if (tid < 16) { s_inf[tid] = 0; s_bas[tid] = 0; s_sum[tid] = 0; }
     if (tid < 2) s_veto[tid] = NO_VETO;
-    if (tid == 0) { s_best[0] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[1] = -1; }
+    if (tid == 0) {
+        s_best[0] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[1] = -1;
+        s_best[2] = __builtin_inf(); reinterpret_cast<long long *>(s_best)[3] = -1;
+    }
     if (tid < 16 * T) s_vmask[tid] = tid < p.n ? p.mask[tid] : 0ULL;
     if (tid < 64) lds_image.s_rbit[tid] = tid < 40 ? p.rbit.gbit[tid] : 0;
     __syncthreads();
@@ -499,7 +502,10 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             if (tid == THREADS - 1) {                                // lexicographic (objective, pattern) minimum: argmin's first-index rule
                 const double bo = s_best[0];
                 const long long bp = reinterpret_cast<long long *>(s_best)[1];
-                if (obj2 < bo || (obj2 == bo && ref_index_less(pat, (unsigned long long)bp, lds_image.s_rbit))) { s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat; }
+                if (obj2 < bo || (obj2 == bo && ref_index_less(pat, (unsigned long long)bp, lds_image.s_rbit))) {
+                    s_best[2] = bo; reinterpret_cast<long long *>(s_best)[3] = bp;             // the old minimum becomes the runner-up
+                    s_best[0] = obj2; reinterpret_cast<long long *>(s_best)[1] = (long long)pat;
+                } else if (obj2 < s_best[2]) { s_best[2] = obj2; reinterpret_cast<long long *>(s_best)[3] = (long long)pat; }
             }
         }
         if constexpr (NODE) {
@@ -518,6 +524,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     if (tid == 0) {
         p.best_obj[blockIdx.x] = sqrt(s_best[0]);
         p.best_pat[blockIdx.x] = reinterpret_cast<long long *>(s_best)[1];
+        if (p.second_obj) { p.second_obj[blockIdx.x] = sqrt(s_best[2]); p.second_pat[blockIdx.x] = reinterpret_cast<long long *>(s_best)[3]; }
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, (unsigned long long)npiv);
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, (unsigned long long)nunconv);
         if (p.n_vetoes && nveto) atomicAdd(p.n_vetoes, (unsigned long long)nveto);

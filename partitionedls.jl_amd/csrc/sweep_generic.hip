@@ -51,6 +51,8 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
 
     double best_obj = __builtin_inf();
     long long best_pat = -1;
+    double second_obj = __builtin_inf();                           // runner-up of this workgroup (near-tie re-rank on the host)
+    long long second_pat = -1;
     unsigned long long npiv = 0, nunconv = 0;
 
     const int64_t total = p.g_end - p.g_begin;
@@ -134,7 +136,10 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
             const double obj2 = T[(size_t)n * ld + n];
             const double obj = sqrt(obj2 > 0.0 ? obj2 : 0.0);
             if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
-            if (obj < best_obj || (obj == best_obj && best_pat >= 0 && ref_index_less(pat, (unsigned long long)best_pat, p.rbit.gbit))) { best_obj = obj; best_pat = (long long)pat; }
+            if (obj < best_obj || (obj == best_obj && best_pat >= 0 && ref_index_less(pat, (unsigned long long)best_pat, p.rbit.gbit))) {
+                second_obj = best_obj; second_pat = best_pat;
+                best_obj = obj; best_pat = (long long)pat;
+            } else if (obj < second_obj) { second_obj = obj; second_pat = (long long)pat; }
             if (p.node_piv && code && tid == 0) {                  // [pivots, blocks, scans] so far; this kernel reports pivots only
                 unsigned *o = p.node_piv + 3 * ((size_t)chain * p.chain_len + (size_t)(g - g0));
                 o[0] = (unsigned)npiv; o[1] = 0; o[2] = 0;
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
     if (tid == 0) {
         p.best_obj[blockIdx.x] = best_obj;
         p.best_pat[blockIdx.x] = best_pat;
+        if (p.second_obj) { p.second_obj[blockIdx.x] = second_obj; p.second_pat[blockIdx.x] = second_pat; }
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
     }

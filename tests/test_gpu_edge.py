@@ -127,6 +127,35 @@ def test_ill_conditioned_model_parity(partls, oracle, noise, tol):
         assert abs(m.t - ref["t"]) < tol
 
 
+@pytest.mark.parametrize("seed", [42, 43, 44])
+def test_beyond_the_gram_form_the_call_reports_it(partls, oracle, seed):
+    """cond(Xo) from 7e5 to 7e7: the fp64 Gram form loses the smallest directions (cond^2 * eps -> 1) and with them columns the
+    reference's QR-based NNLS (Opt.jl:89) would use.  The winner's KKT conditions are verified against the DATA: at each level either
+    the fit equals the oracle's, or the call says PARTLS_ERR_ILL_CONDITIONED — never a silently different model."""
+    reported = 0
+    for noise in (1e-5, 3e-6, 1e-6, 3e-7, 1e-7):
+        rng = np.random.default_rng(seed)
+        N, D, K = 2000, 24, 4
+        Z = rng.standard_normal((N, 6))
+        X = Z @ rng.standard_normal((6, D)) + noise * rng.standard_normal((N, D))
+        grp = np.arange(D) % K
+        P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), grp] = 1
+        y = X @ (rng.random(D) * np.array([1., -2, 3, -1])[grp]) + 0.3 + 0.05 * rng.standard_normal(N)
+        ref = oracle.fit_opt(X, y, P)
+        for alg in (partls.Opt, partls.BnB):
+            try:
+                m, _, rep = partls.fit(alg, X, y, P)
+            except partls.PartlsError as e:
+                assert e.status == partls.lowlevel.ERR_ILL_CONDITIONED, e
+                assert partls.default_context().kkt_violation() > 1e-13
+                reported += 1
+                continue
+            assert abs(rep.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]), (noise, alg)
+            np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-6)
+            assert partls.default_context().kkt_violation() <= 1e-13
+    assert reported >= 4                                   # the two worst levels are certainly out of reach of the Gram form
+
+
 @pytest.mark.parametrize("M", [1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 300, 385])
 def test_gram_virtual_columns_at_tile_boundaries(partls, M):
     """The ones / y columns of Z = [X 1 y] are virtual (they ride on the diagonal 128 x 128 tiles as extra 16 x 16 accumulators); the

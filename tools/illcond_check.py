@@ -1,18 +1,34 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""illcond_check.py — what fit(Opt) returns as the data get ill-conditioned (cond(Xo) ~ 1/noise): objective / model gap to the dense
+oracle, the data-space KKT violation of the winner (partls_get_kkt_violation), leave-one-out vetoes of the sweep, and the status."""
+import sys; sys.path.insert(0, '/root/repo')
 import numpy as np
 import partls_amd
 from oracle import oracle as O
 pls = partls_amd.package()
-rng = np.random.default_rng(42)
-for noise in [1e-2, 1e-3, 1e-4, 1e-5]:
-    N, D, K = 2000, 24, 4
+
+
+def problem(noise, seed=42, N=2000, D=24, K=4):
+    rng = np.random.default_rng(seed)
     Z = rng.standard_normal((N, 6))
     X = Z @ rng.standard_normal((6, D)) + noise * rng.standard_normal((N, D))     # cond(X) ~ 1/noise
     grp = np.arange(D) % K
     P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), grp] = 1
     y = X @ (rng.random(D) * np.array([1., -2, 3, -1])[grp]) + 0.3 + 0.05 * rng.standard_normal(N)
-    ref = O.fit_opt(X, y, P)
-    m, _, rep = pls.fit(pls.Opt, X, y, P)
-    sv = np.linalg.svd(np.hstack([X, np.ones((N,1))]), compute_uv=False)
-    print(f"noise={noise:g} cond(Xo)={sv[0]/sv[-1]:.2e} opt gpu={rep.opt:.12f} ref={ref['opt']:.12f} gap={abs(rep.opt-ref['opt'])/max(1,ref['opt']):.2e} "
-          f"best {rep.best_index}/{ref['best_index']} max|dalpha|={np.abs(m.α-ref['alpha']).max():.2e} max|dbeta|={np.abs(m.β-ref['beta']).max():.2e} |dt|={abs(m.t-ref['t']):.2e}")
+    return X, y, P
+
+
+if __name__ == "__main__":
+    for seed in (42, 43):
+        for noise in [1e-2, 1e-3, 1e-4, 1e-5, 3e-6, 1e-6, 3e-7, 1e-7]:
+            X, y, P = problem(noise, seed)
+            ref = O.fit_opt(X, y, P)
+            ctx = pls.default_context()
+            status = "OK"
+            try:
+                m, _, rep = pls.fit(pls.Opt, X, y, P)
+                opt, bi, a = rep.opt, rep.best_index, m.α
+            except pls.PartlsError as e:
+                status, opt, bi, a = f"status {e.status}", float("nan"), -1, np.full(X.shape[1], np.nan)
+            sv = np.linalg.svd(np.hstack([X, np.ones((X.shape[0], 1))]), compute_uv=False)
+            print(f"seed={seed} noise={noise:g} cond(Xo)={sv[0]/sv[-1]:.2e} {status:9s} kkt={ctx.kkt_violation():.2e} vetoes={ctx.vetoes()} "
+                  f"gap={abs(opt-ref['opt'])/max(1,ref['opt']):.2e} best {bi}/{ref['best_index']} max|dalpha|={np.abs(a-ref['alpha']).max():.2e}")
