@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-patterns", type=int, default=32, help="patterns in the dense CPU baseline sample")
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baselines (0 = min(16, cores))")
-    ap.add_argument("--bnb-cap", type=int, default=20000, help="node cap of the C5 bnb_hard leg")
+    ap.add_argument("--bnb-cap", type=int, default=200000, help="node cap of the C5 bnb_hard leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,7 +117,10 @@ def main():
     def bnb_pass(cap=None):
         ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
         t0 = time.perf_counter()
-        mu, pat, free, bounded = pls.dist.bnb_search(ctx.bnb_bound, K + 1, rank=rank, world=world, device=red_dev, max_nodes=cap)
+        if world == 1:          # in-library search: every node warm-started from its parent's tableau snapshot (partls_bnb_search)
+            mu, pat, free, bounded = ctx.bnb_search(cap or 0)
+        else:                   # frontier batches dealt over the ranks (cold node bounds: a snapshot lives on one GPU only)
+            mu, pat, free, bounded = pls.dist.bnb_search(ctx.bnb_bound, K + 1, rank=rank, world=world, device=red_dev, max_nodes=cap)
         a, b, t, opt = ctx.bnb_leaf(pat, free)
         return dict(opt=opt, nopen=bounded, seconds=time.perf_counter() - t0)
 
@@ -241,11 +244,16 @@ def main():
         torch.cuda.synchronize()
         ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
         t1 = time.perf_counter()
-        mu, pat, free, bounded = pls.dist.bnb_search(ctx.bnb_bound, K + 1, max_nodes=args.bnb_cap)
+        mu, pat, free, bounded = ctx.bnb_search(args.bnb_cap)
         dt = time.perf_counter() - t1
         out["bnb_hard"] = {"target": "y = 1 + 0.1 * noise (wstar = 0)", "nodes_bounded": bounded, "seconds": dt,
                            "nodes_per_s": bounded / dt, "capped": bounded >= args.bnb_cap,
-                           "incumbent": (mu if mu != float("inf") else None)}
+                           "incumbent": (mu if mu != float("inf") else None),
+                           "search": "partls_bnb_search: best-first, device batches, children warm-started from the parent's tableau snapshot"}
+        t1 = time.perf_counter()                             # the same frontier logic with every node from the fresh tableau
+        mu2, _, _, bounded2 = pls.dist.bnb_search(ctx.bnb_bound, K + 1, max_nodes=args.bnb_cap)
+        dt2 = time.perf_counter() - t1
+        out["bnb_hard"]["cold_nodes_per_s"] = bounded2 / dt2
     if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "alt":
         # the sample of the CPU baseline: the GPU's winner + random patterns (reference indexing, K + 1 bits).  The device's answer for
         # every one of them — from the SWEEP's own per-pattern output (all_opt of a faithful enumeration: what ranks the patterns) and

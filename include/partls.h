@@ -154,6 +154,12 @@ partls_status partls_bnb_bound(partls_ctx *ctx, int64_t count, const uint64_t *p
                                double *lb, int32_t *branch);
 partls_status partls_bnb_leaf(partls_ctx *ctx, uint64_t pat, uint64_t free_groups,
                               double *alpha, double *beta, double *t, double *opt);
+/* The search itself (what partls_fit_bnb / partls_bnb_prepared run before partls_bnb_leaf): best-first frontier, device batches,
+ * every node warm-started from its parent's final tableau, which stays in HBM while the node has children in the frontier
+ * (BnB.jl:120-124: a child is the parent's constraint set plus one group).  Returns the incumbent node (pat, free_groups), its
+ * value *mu and the number of nodes bounded.  max_nodes > 0 stops the search there (measurement; *mu = +inf when no feasible
+ * node was met yet); max_nodes <= 0 runs to optimality. */
+partls_status partls_bnb_search(partls_ctx *ctx, int64_t max_nodes, double *mu, uint64_t *pat, uint64_t *free_groups, int64_t *nodes);
 
 /* ---- predict(α, β, t, P, X)  — replaces PartitionedLS.jl:132-134: yhat = X*(P.*α)*β .+ t ------------------------------ */
 partls_status partls_predict(partls_ctx *ctx, const double *X, int64_t N, int64_t M, int64_t ldX,

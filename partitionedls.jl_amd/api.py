@@ -186,6 +186,12 @@ class Context:
                                             br.ctypes.data_as(C.POINTER(C.c_int32))))
         return lb, br
 
+    def bnb_search(self, max_nodes=0):
+        """The BnB search on a prepared faithful context (warm-started node bounds): (mu, pat, free, nodes_bounded)."""
+        mu = C.c_double(); pat = C.c_uint64(); fr = C.c_uint64(); nn = C.c_int64()
+        _check(L.lib().partls_bnb_search(self._h, int(max_nodes), C.byref(mu), C.byref(pat), C.byref(fr), C.byref(nn)))
+        return mu.value, pat.value, fr.value, nn.value
+
     def bnb_leaf(self, pat, free):
         N, M, K = self._shape
         a = np.zeros(M); b = np.zeros(K)

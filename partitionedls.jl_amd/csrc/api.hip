@@ -642,6 +642,9 @@ partls_status partls_create(int device, partls_ctx **out)
     if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
+    c->knobs.bnb_cold = getenv("PARTLS_BNB_COLD") != nullptr;
+    if (const char *e = getenv("PARTLS_BNB_BATCH")) c->knobs.bnb_batch = atoi(e);
+    if (const char *e = getenv("PARTLS_BNB_POOL_MB")) c->knobs.bnb_pool_mb = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_FAULT")) c->knobs.coop_fault = atoi(e);
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
@@ -675,8 +678,10 @@ void partls_destroy(partls_ctx *c)
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
                           &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
                           &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic, &c->altA, &c->altGA, &c->altHg,
-                          &c->nodePiv, &c->maskInt, &c->allOptRef};
+                          &c->nodePiv, &c->maskInt, &c->allOptRef, &c->bnbIn, &c->bnbOut};
         for (DevBuf *b : bufs) b->release();
+        for (void *q : c->bnbChunks) (void)hipFree(q);
+        c->bnbChunks.clear();
         c->hG.release();
         if (c->hTab) (void)hipHostFree(c->hTab);
         if (c->hBasic) (void)hipHostFree(c->hBasic);

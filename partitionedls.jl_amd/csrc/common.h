@@ -68,6 +68,13 @@ struct SweepParams {
     double *node_tab;
     int8_t *node_basic;
     unsigned *node_piv;          // optional (see above)
+    // optional (register kernel, node mode, chain_len == 1): tableau SNAPSHOTS — warm starts of BnB node bounds (BnB.jl:120-124: a child
+    // is its parent's problem plus one group's sign constraint, so it starts from the parent's final tableau and exchanges only that
+    // group's wrong-signed variables).  node_src[c]: snapshot node c starts from (nullptr: the fresh tableau T0); node_dst[c]: where its
+    // final state is stored (nullptr: nowhere).  A snapshot = sweep_reg_t0_doubles(T) doubles in the layout of T0 (tiles, rhs column,
+    // corner) followed by 16 T basis flags (bytes).
+    const double *const *node_src;
+    double *const *node_dst;
     // cooperative single-node kernel only: continue from the tableau / basis left in `scratch` by the previous launch
     // (warm start of consecutive Alt alpha-steps) instead of reloading T0
     int resume;
@@ -116,6 +123,11 @@ hipError_t launch_prep(const double *G, int ldg, int M, double eta, const uint64
 int        walk_flipped_bit(int chain, int step, int kbits, int seg_len, int nseg);
 hipError_t launch_walk_codes(const uint64_t *mask, int n, int kbits, int chains, int L, int seg_len, int nseg, int8_t *codes, hipStream_t s);
 hipError_t launch_pattern_gather(const double *in, int64_t npat, int kbits, const BitOrder &order, double *out, hipStream_t s);
+
+// BnB node batches (misc.hip): per-variable constraint codes of the nodes (pat, free) and (bound, branch) from their solutions
+hipError_t launch_bnb_codes(const uint64_t *mask_tab, int n, const uint64_t *pat, const uint64_t *free_, int cnt, int8_t *codes, hipStream_t s);
+hipError_t launch_bnb_nu(const double *sol, const double *obj2, int n, const double *scale, const uint64_t *mask_tab, int Kp,
+                         const uint64_t *free_, int cnt, double *lb, int *branch, hipStream_t s);
 
 // residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
 // beta-step system of fit(Alt): Hg[k * (Kp + 1) + k2] = H[k][k2] (k2 < Kp), g[k] (k2 = Kp); GA is (M + 1) x Kp scratch

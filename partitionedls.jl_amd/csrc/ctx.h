@@ -52,6 +52,9 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    int bnb_batch = 1024;        // PARTLS_BNB_BATCH: nodes bounded per device batch of the BnB search
+    int bnb_pool_mb = 16384;     // PARTLS_BNB_POOL_MB: cap of the tableau-snapshot pool of the BnB search (warm-started node bounds)
+    bool bnb_cold = false;       // PARTLS_BNB_COLD: every BnB node from the fresh tableau (A/B tests)
     int coop_fault = 0;          // PARTLS_COOP_FAULT (tests): make the cooperative kernel's grid barrier time out (see SweepParams)
     bool no_tab_refine = false;  // PARTLS_NO_TAB_REFINE: refinement by host Cholesky even when the node solve left its tableau (A/B tests)
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
@@ -90,7 +93,12 @@ struct partls_ctx {
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD /* + maskTabP, permP: one upload */, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
         wdev, partial, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic, altA, altGA, altHg,
-        nodePiv, maskInt, allOptRef;
+        nodePiv, maskInt, allOptRef, bnbIn, bnbOut;
+    // BnB: tableau snapshots of open nodes (solvers.hip: SnapshotPool), kept across fits; host staging of a node batch
+    std::vector<void *> bnbChunks;
+    size_t bnbSlotBytes = 0;
+    std::vector<uint64_t> bnbHostIn;
+    std::vector<char> bnbHostOut;
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
     std::vector<double> hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)

@@ -159,6 +159,66 @@ hipError_t launch_walk_codes(const uint64_t *mask, int n, int kbits, int chains,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// BnB node batches (solvers.hip), both ends of a batch on the device so that only (pat, free) goes up and (bound, branch) comes back:
+//   codes: constraint of tableau variable v in node i — its branched groups each contribute alpha >= 0 or <= 0 (the Sigma of
+//          BnB.jl:120-121 accumulates them); none -> free (2), both kinds -> forced to 0 (BnB.jl:74-79);
+//   nu:    lb = sqrt(objective^2) (BnB.jl:69-92) and branch = argmax_k nu_k, nu_k = sum_{i<j in group k} max(0, -w_i w_j) =
+//          (sum of the positive w)(sum of the |negative w|) over the variables of group k (BnB.jl:42-57,107,117); only groups that
+//          are still free can mix signs; -1 when every nu_k is 0: the relaxed solution is feasible (BnB.jl:109-115).
+//          Lane k walks the variables in tableau order (fixed summation order: run-to-run reproducible).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void bnb_codes_kernel(const uint64_t *__restrict__ mask_tab, int n, const uint64_t *__restrict__ pat,
+                                 const uint64_t *__restrict__ free_, int8_t *__restrict__ codes)
+{
+    const uint64_t pt = pat[blockIdx.x], fr = free_[blockIdx.x];
+    for (int v = threadIdx.x; v < n; v += blockDim.x) {
+        const uint64_t br = mask_tab[v] & ~fr;
+        const bool pos = (br & pt) != 0, neg = (br & ~pt) != 0;
+        codes[(size_t)blockIdx.x * n + v] = (int8_t)(!br ? 2 : (pos && neg ? 0 : (pos ? 1 : -1)));
+    }
+}
+
+__global__ __launch_bounds__(64) void bnb_nu_kernel(const double *__restrict__ sol, const double *__restrict__ obj2, int n,
+                                                    const double *__restrict__ scale, const uint64_t *__restrict__ mask_tab, int Kp,
+                                                    const uint64_t *__restrict__ free_, double *__restrict__ lb, int *__restrict__ branch)
+{
+    __shared__ double nu[64];
+    const int i = blockIdx.x, k = threadIdx.x;
+    const uint64_t fr = free_[i];
+    double pos = 0.0, neg = 0.0;
+    if (k < Kp && ((fr >> k) & 1ULL)) {
+        const double *w = sol + (size_t)i * n;
+        for (int v = 0; v < n; ++v) {
+            if (!((mask_tab[v] >> k) & 1ULL)) continue;
+            const double wv = w[v] * scale[v];
+            if (wv > 0.0) pos += wv; else neg -= wv;
+        }
+    }
+    nu[k] = pos * neg;
+    __syncthreads();
+    if (k == 0) {
+        int kbest = -1;
+        double nubest = 0.0;
+        for (int g = 0; g < Kp; ++g) if (nu[g] > nubest) { nubest = nu[g]; kbest = g; }     // argmax: first maximal index
+        const double o2 = obj2[i];
+        lb[i] = sqrt(o2 > 0.0 ? o2 : 0.0);
+        branch[i] = kbest;
+    }
+}
+
+hipError_t launch_bnb_codes(const uint64_t *mask_tab, int n, const uint64_t *pat, const uint64_t *free_, int cnt, int8_t *codes, hipStream_t s)
+{
+    hipLaunchKernelGGL(bnb_codes_kernel, dim3(cnt), dim3(256), 0, s, mask_tab, n, pat, free_, codes);
+    return hipGetLastError();
+}
+hipError_t launch_bnb_nu(const double *sol, const double *obj2, int n, const double *scale, const uint64_t *mask_tab, int Kp,
+                         const uint64_t *free_, int cnt, double *lb, int *branch, hipStream_t s)
+{
+    hipLaunchKernelGGL(bnb_nu_kernel, dim3(cnt), dim3(64), 0, s, sol, obj2, n, scale, mask_tab, Kp, free_, lb, branch);
+    return hipGetLastError();
+}
+
 // all_opt leaves the sweep indexed by the INTERNAL pattern (group k on bit gbit[k]); the boundary indexes it by the reference's
 __global__ void pattern_gather_kernel(const double *__restrict__ in, int64_t npat, int kbits, BitOrder order, double *__restrict__ out)
 {

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <queue>
 
 using namespace partls;
@@ -44,6 +45,126 @@ bool solve_dense(std::vector<double> &H, std::vector<double> &g, int n)
         g[(size_t)i] = s / H[(size_t)i * n + i];
     }
     return true;
+}
+
+// ---- BnB node batches on the device ---------------------------------------------------------------------------------------------
+// Snapshot pool: the final state of a bounded node (tableau tiles, rhs column, corner, basis flags: ~0.3 MB at n = 257) stays in
+// HBM while the node has children in the frontier — a child is its parent's problem plus one group's sign constraint
+// (BnB.jl:120-124), so it starts from the parent's tableau and exchanges only that group's wrong-signed variables instead of
+// ~n/2 variables from scratch.  Slots live in chunks that are allocated on demand and kept by the context (288 GB of HBM:
+// the default cap of 16 GB holds ~50 000 open nodes at n = 257); when the pool is full a node simply leaves no snapshot and
+// its children start from the fresh tableau.
+struct SnapshotPool {
+    partls_ctx *c;
+    size_t slot_bytes = 0;
+    static constexpr int CHUNK = 512;
+    std::vector<int> free_list, refs;
+    size_t max_slots = 0;
+
+    hipError_t begin(size_t bytes)
+    {
+        slot_bytes = (bytes + 255) & ~(size_t)255;
+        if (c->bnbSlotBytes != slot_bytes) {                       // another tableau size: the old chunks are useless
+            for (void *q : c->bnbChunks) (void)hipFree(q);
+            c->bnbChunks.clear();
+            c->bnbSlotBytes = slot_bytes;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        size_t cap = (size_t)c->knobs.bnb_pool_mb << 20;
+        cap = std::min(cap, free_b / 2 + c->bnbChunks.size() * CHUNK * slot_bytes);
+        max_slots = cap / slot_bytes;
+        free_list.clear();
+        refs.assign(c->bnbChunks.size() * CHUNK, 0);
+        for (int i = (int)refs.size() - 1; i >= 0; --i) free_list.push_back(i);
+        return hipSuccess;
+    }
+    double *ptr(int slot) const { return reinterpret_cast<double *>(static_cast<char *>(c->bnbChunks[(size_t)slot / CHUNK]) + (size_t)(slot % CHUNK) * slot_bytes); }
+    int alloc()                                                    // -1: pool exhausted
+    {
+        if (free_list.empty()) {
+            if ((c->bnbChunks.size() + 1) * CHUNK > max_slots) return -1;
+            void *q = nullptr;
+            if (hipMalloc(&q, (size_t)CHUNK * slot_bytes) != hipSuccess) { (void)hipGetLastError(); max_slots = 0; return -1; }
+            const int base = (int)c->bnbChunks.size() * CHUNK;
+            c->bnbChunks.push_back(q);
+            refs.resize((size_t)base + CHUNK, 0);
+            for (int i = CHUNK - 1; i >= 0; --i) free_list.push_back(base + i);
+        }
+        const int sl = free_list.back();
+        free_list.pop_back();
+        refs[(size_t)sl] = 0;
+        return sl;
+    }
+    void release(int slot) { if (slot >= 0 && --refs[(size_t)slot] <= 0) free_list.push_back(slot); }
+    void drop(int slot) { if (slot >= 0) free_list.push_back(slot); }          // a slot nobody references
+};
+
+// Bound `cnt` nodes (pat, free) on the register kernel: codes, node solves (warm-started from src[i] when given, final state
+// stored to dst[i] when given) and (bound, branch) all on the device; one upload, one download, one synchronisation per batch.
+partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, const uint64_t *free_, const double *const *src,
+                              double *const *dst, double *lb, int32_t *branch, unsigned long long *unconv)
+{
+    const int n = c->n, Kp = (int)c->K + 1;
+    c->tab_valid = false;
+    c->coop_state_valid = false;
+    if (unconv) *unconv = 0;
+    if (cnt == 0) return PARTLS_OK;
+    const bool snaps = src != nullptr || dst != nullptr;
+    // input block: [pat | free | src | dst] (8 B each per node); output block: [counters 4 x 8 B | lb (cnt) | branch (cnt x 4 B)]
+    const size_t in_words = (snaps ? 4 : 2) * cnt, out_bytes = 32 + cnt * 8 + ((cnt * 4 + 7) & ~(size_t)7);
+    PARTLS_HIP_CHECK(c->bnbIn.ensure(in_words * 8));
+    PARTLS_HIP_CHECK(c->bnbOut.ensure(out_bytes));
+    PARTLS_HIP_CHECK(c->nodeCode.ensure(cnt * (size_t)n));
+    PARTLS_HIP_CHECK(c->nodeSol.ensure((4 + cnt + cnt * (size_t)n) * sizeof(double)));
+    PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 4 * 4096)));
+    PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
+    PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
+    c->bnbHostIn.resize(in_words);
+    std::memcpy(c->bnbHostIn.data(), pat, cnt * 8);
+    std::memcpy(c->bnbHostIn.data() + cnt, free_, cnt * 8);
+    if (snaps) {
+        for (size_t i = 0; i < cnt; ++i) {
+            c->bnbHostIn[2 * cnt + i] = (uint64_t)(uintptr_t)(src ? src[i] : nullptr);
+            c->bnbHostIn[3 * cnt + i] = (uint64_t)(uintptr_t)(dst ? dst[i] : nullptr);
+        }
+    }
+    uint64_t *din = c->bnbIn.as<uint64_t>();
+    char *dout = static_cast<char *>(c->bnbOut.p);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(din, c->bnbHostIn.data(), in_words * 8, hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemsetAsync(dout, 0, 32, c->stream));
+    PARTLS_HIP_CHECK(launch_bnb_codes(c->maskTabP, n, din, din + cnt, (int)cnt, c->nodeCode.as<int8_t>(), c->stream));
+    SweepParams p{};
+    p.n = n; p.kbits = c->kbits;
+    p.mask = c->maskTabP;
+    p.scratch = c->scratch.as<double>();
+    p.g_begin = 0; p.g_end = (int64_t)cnt; p.chain_len = 1;
+    p.tol = c->tol; p.piv_eps = 1e-11; p.max_rounds = 20 * (n + 1);
+    p.best_obj = c->bestObj.as<double>(); p.best_pat = c->bestPat.as<int64_t>();
+    p.n_unconverged = reinterpret_cast<unsigned long long *>(dout);
+    p.n_pivots = p.n_unconverged + 1;
+    p.n_vetoes = p.n_unconverged + 2;
+    p.node_code = c->nodeCode.as<int8_t>();
+    p.node_obj2 = c->nodeSol.as<double>() + 4; p.node_sol = c->nodeSol.as<double>() + 4 + cnt; p.node_ld = n;
+    if (snaps) {
+        p.node_src = reinterpret_cast<const double *const *>(din + 2 * cnt);
+        p.node_dst = reinterpret_cast<double *const *>(din + 3 * cnt);
+    }
+    p.T0 = c->T0reg.as<double>();
+    PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, (int)std::min<size_t>(cnt, 2048), c->stream));
+    double *dlb = reinterpret_cast<double *>(dout + 32);
+    int *dbr = reinterpret_cast<int *>(dout + 32 + cnt * 8);
+    PARTLS_HIP_CHECK(launch_bnb_nu(p.node_sol, p.node_obj2, n, c->scale.as<double>(), c->maskTabP, Kp, din + cnt, (int)cnt, dlb, dbr, c->stream));
+    c->bnbHostOut.resize(out_bytes);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->bnbHostOut.data(), dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    unsigned long long counters[4];
+    std::memcpy(counters, c->bnbHostOut.data(), 32);
+    std::memcpy(lb, c->bnbHostOut.data() + 32, cnt * 8);
+    std::memcpy(branch, c->bnbHostOut.data() + 32 + cnt * 8, cnt * 4);
+    if (unconv) *unconv = counters[0];
+    c->last_pivots = counters[1]; c->last_vetoes = counters[2];
+    return PARTLS_OK;
 }
 
 }  // namespace
@@ -183,6 +304,13 @@ partls_status partls_bnb_bound(partls_ctx *c, int64_t count, const uint64_t *pat
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (count < 0 || (count > 0 && (!pat || !free_ || !lb || !branch))) { set_error("partls_bnb_bound: bad argument"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    if (c->use_reg) {                                          // codes, solves and (bound, branch) on the device (misc.hip)
+        unsigned long long unc = 0;
+        partls_status st2 = bnb_bound_batch(c, (size_t)count, pat, free_, nullptr, nullptr, lb, branch, &unc);
+        if (st2 != PARTLS_OK) return st2;
+        if (unc) { set_error("partls_bnb_bound: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+        return PARTLS_OK;
+    }
     const int Mp = (int)c->M + 1, Kp = (int)c->K + 1, n = c->n;
     // per-variable constraint of a node: the branched groups of the variable each contribute alpha >= 0 or alpha <= 0 (the Σ of
     // BnB.jl:120-121 accumulates them); none -> free, both kinds -> the variable is forced to 0 (BnB.jl:74-79)
@@ -272,48 +400,95 @@ partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, doubl
     return PARTLS_OK;
 }
 
-// fit_BnB (BnB.jl:94-132) as a best-first search: frontier ordered by the parent's bound, nodes bounded in device batches of 512,
-// the incumbent prunes (BnB.jl:102).  Same optimum as the reference's depth-first recursion; the node count is not.
+// fit_BnB (BnB.jl:94-132) as a best-first search: frontier ordered by the parent's bound, nodes bounded in device batches, the
+// incumbent prunes (BnB.jl:102).  Same optimum as the reference's depth-first recursion; the node count is not.  On the register
+// kernel every node starts from its parent's final tableau (SnapshotPool): the reference's recursion hands the child the parent's
+// constraint set plus one group (BnB.jl:120-124), here it also inherits the parent's basis.
+// max_nodes > 0 (measurement): stop after that many bounded nodes and report the incumbent so far (*mu = inf when there is none).
+partls_status partls_bnb_search(partls_ctx *c, int64_t max_nodes, double *mu_out, uint64_t *pat_out, uint64_t *free_out, int64_t *nodes_out)
+{
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_search: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (!mu_out || !pat_out || !free_out) { set_error("partls_bnb_search: NULL output"); return PARTLS_ERR_BAD_ARG; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    const int Kp = (int)c->K + 1;
+    struct Node { double key; uint64_t pat, free_; unsigned long long seq; int slot; };     // slot: the PARENT's snapshot (-1: none)
+    struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
+    std::priority_queue<Node, std::vector<Node>, Cmp> frontier;
+    unsigned long long seq = 0;
+    frontier.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, seq++, -1});        // root: everything free (Σ = [], BnB.jl:33)
+    double mu = INFINITY;
+    uint64_t best_pat = 0, best_free = ((uint64_t)1 << Kp) - 1;
+    int64_t bounded = 0;
+    const bool warm = c->use_reg && !c->knobs.bnb_cold;
+    const size_t BATCH = (size_t)std::max(1, c->knobs.bnb_batch);
+    SnapshotPool pool{c};
+    if (warm) PARTLS_HIP_CHECK(pool.begin((sweep_reg_t0_doubles(c->T)) * sizeof(double) + (size_t)16 * c->T));
+    std::vector<uint64_t> bp, bf;
+    std::vector<int> pslot, dslot;
+    std::vector<const double *> srcp;
+    std::vector<double *> dstp;
+    std::vector<double> lb;
+    std::vector<int32_t> br;
+    unsigned long long unconv_total = 0;
+    while (!frontier.empty() && !(max_nodes > 0 && bounded >= max_nodes)) {
+        bp.clear(); bf.clear(); pslot.clear();
+        while (!frontier.empty() && bp.size() < BATCH) {
+            const Node nd = frontier.top();
+            frontier.pop();
+            if (nd.key >= mu) { if (warm) pool.release(nd.slot); continue; }   // its bound can only be >= the parent's
+            bp.push_back(nd.pat); bf.push_back(nd.free_); pslot.push_back(nd.slot);
+        }
+        if (bp.empty()) break;
+        const size_t cnt = bp.size();
+        lb.resize(cnt); br.resize(cnt);
+        partls_status st;
+        if (c->use_reg) {
+            unsigned long long unc = 0;
+            if (warm) {
+                dslot.resize(cnt); srcp.resize(cnt); dstp.resize(cnt);
+                for (size_t i = 0; i < cnt; ++i) {
+                    // a node whose groups are all branched cannot branch again: no snapshot needed
+                    dslot[i] = __builtin_popcountll(bf[i]) > 0 ? pool.alloc() : -1;
+                    srcp[i] = pslot[i] >= 0 ? pool.ptr(pslot[i]) : nullptr;
+                    dstp[i] = dslot[i] >= 0 ? pool.ptr(dslot[i]) : nullptr;
+                }
+                st = bnb_bound_batch(c, cnt, bp.data(), bf.data(), srcp.data(), dstp.data(), lb.data(), br.data(), &unc);
+            } else {
+                st = bnb_bound_batch(c, cnt, bp.data(), bf.data(), nullptr, nullptr, lb.data(), br.data(), &unc);
+            }
+            unconv_total += unc;
+        } else {
+            st = partls_bnb_bound(c, (int64_t)cnt, bp.data(), bf.data(), lb.data(), br.data());
+        }
+        if (st != PARTLS_OK) return st;
+        for (size_t i = 0; i < cnt; ++i) {
+            ++bounded;
+            const int mine = warm ? dslot[i] : -1;
+            if (warm) pool.release(pslot[i]);                              // this child no longer needs its parent's tableau
+            if (lb[i] >= mu) { if (warm) pool.drop(mine); continue; }      // BnB.jl:102
+            if (br[i] < 0) { mu = lb[i]; best_pat = bp[i]; best_free = bf[i]; if (warm) pool.drop(mine); continue; }   // BnB.jl:109-115
+            const uint64_t bit = 1ULL << br[i];
+            if (mine >= 0) pool.refs[(size_t)mine] = 2;                    // both children start from this node's tableau
+            frontier.push({lb[i], bp[i] | bit, bf[i] & ~bit, seq++, mine});     // α_pk >= 0 first (BnB.jl:120,123)
+            frontier.push({lb[i], bp[i] & ~bit, bf[i] & ~bit, seq++, mine});    // α_pk <= 0
+        }
+    }
+    *mu_out = mu; *pat_out = best_pat; *free_out = best_free;
+    if (nodes_out) *nodes_out = bounded;
+    if (unconv_total) { set_error("partls_bnb_search: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+
 partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
 {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_prepared: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (!alpha || !beta || !t || !opt) { set_error("partls_fit_bnb: NULL argument"); return PARTLS_ERR_BAD_ARG; }
-    const int Kp = (int)c->K + 1;
-    struct Node { double key; uint64_t pat, free_; unsigned long long seq; };
-    struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
-    std::priority_queue<Node, std::vector<Node>, Cmp> frontier;
-    unsigned long long seq = 0;
-    frontier.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, seq++});            // root: everything free (Σ = [], BnB.jl:33)
     double mu = INFINITY;
     uint64_t best_pat = 0, best_free = 0;
-    bool have = false;
     int64_t bounded = 0;
-    const size_t BATCH = 512;
-    std::vector<uint64_t> bp, bf;
-    std::vector<double> lb;
-    std::vector<int32_t> br;
-    while (!frontier.empty()) {
-        bp.clear(); bf.clear();
-        while (!frontier.empty() && bp.size() < BATCH) {
-            const Node nd = frontier.top();
-            frontier.pop();
-            if (nd.key >= mu) continue;                                    // its bound can only be >= the parent's
-            bp.push_back(nd.pat); bf.push_back(nd.free_);
-        }
-        if (bp.empty()) break;
-        lb.resize(bp.size()); br.resize(bp.size());
-        partls_status st = partls_bnb_bound(c, (int64_t)bp.size(), bp.data(), bf.data(), lb.data(), br.data());
-        if (st != PARTLS_OK) return st;
-        for (size_t i = 0; i < bp.size(); ++i) {
-            ++bounded;
-            if (lb[i] >= mu) continue;                                     // BnB.jl:102
-            if (br[i] < 0) { mu = lb[i]; best_pat = bp[i]; best_free = bf[i]; have = true; continue; }   // BnB.jl:109-115
-            const uint64_t bit = 1ULL << br[i];
-            frontier.push({lb[i], bp[i] | bit, bf[i] & ~bit, seq++});      // α_pk >= 0 first (BnB.jl:120,123)
-            frontier.push({lb[i], bp[i] & ~bit, bf[i] & ~bit, seq++});     // α_pk <= 0
-        }
-    }
-    if (!have) { set_error("partls_fit_bnb: no feasible leaf found"); return PARTLS_ERR_NOT_CONVERGED; }
+    partls_status st = partls_bnb_search(c, 0, &mu, &best_pat, &best_free, &bounded);
+    if (st != PARTLS_OK) return st;
+    if (!(mu < INFINITY)) { set_error("partls_fit_bnb: no feasible leaf found"); return PARTLS_ERR_NOT_CONVERGED; }
     if (nopen) *nopen = bounded;
     return partls_bnb_leaf(c, best_pat, best_free, alpha, beta, t, opt);
 }

@@ -292,11 +292,21 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
         const int64_t g0 = p.g_begin + (int64_t)chain * clen;
         const int glen = (int)((g0 + clen < p.g_end) ? clen : p.g_end - g0);
         STAMP(5);
+        const double *src = p.T0;
+        if constexpr (NODE) {                                         // warm start from a snapshot (BnB children), wave-uniform
+            if (p.node_src) {
+                const double *snap = p.node_src[chain];
+                if (snap) src = snap;
+            }
+        }
 #pragma unroll
-        for (int s = 0; s < L::CNT; ++s) S[s] = p.T0[(size_t)(s + L::OFF) * 256 + t8];
-        q = (tid < 16 * T) ? p.T0[(size_t)nslots(T) * 256 + tid] : 0.0;
-        corner = p.T0[(size_t)nslots(T) * 256 + 16 * T];
+        for (int s = 0; s < L::CNT; ++s) S[s] = src[(size_t)(s + L::OFF) * 256 + t8];
+        q = (tid < 16 * T) ? src[(size_t)nslots(T) * 256 + tid] : 0.0;
+        corner = src[(size_t)nslots(T) * 256 + 16 * T];
         basic = false;
+        if constexpr (NODE) {
+            if (src != p.T0 && tid < 16 * T) basic = reinterpret_cast<const int8_t *>(src + (nslots(T) * 256 + 16 * T + 8))[tid] != 0;
+        }
         STAMP(6);
 
         for (int gi = 0; gi < glen; ++gi) {
@@ -511,6 +521,18 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
         if constexpr (NODE) {
             if (has_var) p.node_sol[(size_t)chain * p.node_ld + tid] = basic ? q : 0.0;
             if (tid == 0) p.node_obj2[chain] = corner;
+            if (p.node_dst) {                                     // snapshot of the final state: what a child node starts from
+                double *snap = p.node_dst[chain];
+                if (snap && (H == 0 || T > 1)) {
+#pragma unroll
+                    for (int s = 0; s < L::CNT; ++s) snap[(size_t)(s + L::OFF) * 256 + t8] = S[s];
+                    if (tid < 16 * T) {
+                        snap[(size_t)nslots(T) * 256 + tid] = q;
+                        reinterpret_cast<int8_t *>(snap + (nslots(T) * 256 + 16 * T + 8))[tid] = basic ? 1 : 0;
+                    }
+                    if (tid == 0) snap[(size_t)nslots(T) * 256 + 16 * T] = corner;
+                }
+            }
             if (p.node_tab && (H == 0 || T > 1)) {                // final tableau + basis, same layout as T0 (half 1 of T = 1 owns nothing)
                 double *tab = p.node_tab + (size_t)chain * (nslots(T) * 256 + 16 * T + 8);
 #pragma unroll

@@ -141,3 +141,48 @@ def test_alt_determinism_like_the_reference_suite(partls):
             last = rep.opt
         else:
             assert abs(rep.opt - last) <= 1e-6
+
+
+def _branching_problem(seed=7, N=400, D=36, K=6):
+    """a target the partitioned model cannot explain well: the relaxation at the root mixes signs in most groups, so BnB branches"""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    y = X @ rng.standard_normal(D) + 0.2 * rng.standard_normal(N)            # unconstrained signs inside every group
+    return X, y, P
+
+
+@pytest.mark.parametrize("mode", ["warm", "cold", "tiny_pool", "batch7"])
+def test_bnb_warm_started_bounds_equal_cold_ones(partls, oracle, monkeypatch, mode):
+    """fit(BnB) with every node started from its parent's tableau snapshot (default), from the fresh tableau (PARTLS_BNB_COLD), with
+    a snapshot pool too small for the frontier (children of unrecorded nodes start cold) and with odd batch sizes: same optimum and
+    model as the oracle's depth-first search (BnB.jl:94-132) and as Opt."""
+    if mode == "cold":
+        monkeypatch.setenv("PARTLS_BNB_COLD", "1")
+    if mode == "tiny_pool":
+        monkeypatch.setenv("PARTLS_BNB_POOL_MB", "1")
+    if mode == "batch7":
+        monkeypatch.setenv("PARTLS_BNB_BATCH", "7")
+    X, y, P = _branching_problem()
+    ref = oracle.fit_bnb(X, y, P)
+    ctx = partls.Context(0)
+    ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    a, b, t, opt, nopen = ctx.bnb_prepared()
+    mu, pat, free, nodes = ctx.bnb_search(0)
+    ctx.close()
+    assert nopen > 20 and nodes == nopen                                      # it really branched; the search is deterministic
+    assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(mu - opt) <= 1e-9 * max(1.0, opt)
+    np.testing.assert_allclose(partls.predict(partls.PartLSFitResult(a, b, t, P), X),
+                               oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"]), atol=1e-7)
+    m, _, rep = partls.fit(partls.Opt, X, y, P)
+    assert abs(rep.opt - opt) <= 1e-9 * max(1.0, opt)
+
+
+def test_bnb_search_node_cap(partls):
+    X, y, P = _branching_problem(seed=8, D=48, K=8)
+    ctx = partls.Context(0)
+    ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    mu_full, _, _, n_full = ctx.bnb_search(0)
+    mu_cap, _, _, n_cap = ctx.bnb_search(5)
+    ctx.close()
+    assert 5 <= n_cap <= 5 + 1024 and n_cap <= n_full and (mu_cap >= mu_full)
