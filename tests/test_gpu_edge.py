@@ -150,8 +150,11 @@ def test_beyond_the_gram_form_the_call_reports_it(partls, oracle, seed):
                 assert partls.default_context().kkt_violation() > 1e-13
                 reported += 1
                 continue
-            assert abs(rep.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]), (noise, alg)
-            np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-6)
+            # a fit that passed the data-space check is never worse than the oracle's; it may be (slightly) BETTER: at cond > 1e6 the
+            # oracle's own dependence rule (oracle/partls_oracle.h) drops columns a KKT-verified solution still uses
+            assert rep.opt <= ref["opt"] * (1 + 1e-9), (noise, alg)
+            if abs(rep.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]):
+                np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-6)
             assert partls.default_context().kkt_violation() <= 1e-13
     assert reported >= 4                                   # the two worst levels are certainly out of reach of the Gram form
 
