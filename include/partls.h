@@ -194,9 +194,10 @@ partls_status partls_get_pivots(const partls_ctx *ctx, int64_t *pivots);
 partls_status partls_get_vetoes(const partls_ctx *ctx, int64_t *vetoes);
 /* data-space KKT violation of the model the last partls_opt_finish / partls_bnb_leaf (hence fit(Opt), fit(BnB)) returned: the largest
  * of |x_m'r| (passive or free variable), f_m x_m'r (variable at its bound) and -f_m w_m / max|w| over every variable, r = yo - Xo w
- * computed from the data, in units of ||x_m|| ||y||.  ~1e-13 on well-conditioned data; above 1e-8 (PARTLS_KKT_TOL) the call
- * returns PARTLS_ERR_ILL_CONDITIONED (see there). */
-partls_status partls_get_kkt_violation(const partls_ctx *ctx, double *violation);
+ * computed from the data, in units of ||x_m|| ||y||.  <= 3e-15 on data the Gram form resolves; above 1e-12 (PARTLS_KKT_TOL) the call
+ * returns PARTLS_ERR_ILL_CONDITIONED (see there).  min_pivot (optional): the smallest leave-one-out pivot of that model's basis on the
+ * unit-diagonal scale, a lower bound of 1 / cond(G_BB) (0 when unknown). */
+partls_status partls_get_kkt_violation(const partls_ctx *ctx, double *violation, double *min_pivot);
 /* debugging / tests: copy the Gram products of the prepared problem to the host: G ((M+2) x (M+2), column-major,
  * variables ordered [features, intercept, y]), i.e. G, c = G[:, M+1], yy = G[M+1, M+1], after η has been applied. */
 partls_status partls_get_gram(const partls_ctx *ctx, double *G_aug);

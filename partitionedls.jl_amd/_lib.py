@@ -58,7 +58,7 @@ SYMBOLS = [
     ("partls_get_gram", C.c_int, [C.c_void_p, _dp]),
     ("partls_get_pivots", C.c_int, [C.c_void_p, _ip]),
     ("partls_get_vetoes", C.c_int, [C.c_void_p, _ip]),
-    ("partls_get_kkt_violation", C.c_int, [C.c_void_p, _dp]),
+    ("partls_get_kkt_violation", C.c_int, [C.c_void_p, _dp, _dp]),
 ]
 
 _lib = None

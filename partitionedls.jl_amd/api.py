@@ -217,8 +217,14 @@ class Context:
     def kkt_violation(self):
         """data-space KKT violation of the last finished winner (include/partls.h: partls_get_kkt_violation)"""
         v = C.c_double()
-        _check(L.lib().partls_get_kkt_violation(self._h, C.byref(v)))
+        _check(L.lib().partls_get_kkt_violation(self._h, C.byref(v), None))
         return v.value
+
+    def min_pivot(self):
+        """smallest leave-one-out pivot of the last finished model's basis (lower bound of 1 / cond of its Gram block)"""
+        v = C.c_double(); mp = C.c_double()
+        _check(L.lib().partls_get_kkt_violation(self._h, C.byref(v), C.byref(mp)))
+        return mp.value
 
     def gram(self):
         N, M, K = self._shape

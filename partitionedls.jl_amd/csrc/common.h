@@ -106,6 +106,7 @@ hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   //
 bool       sweep_reg_supported(int n);
 int        sweep_reg_tiles(int n);
 size_t     sweep_reg_t0_doubles(int T);                  // size of the tile-cyclic initial tableau
+int        sweep_reg_concurrency(int T);                 // chains a CU runs at the same time (1: the 512-thread kernel, > 1: small tableaus)
 hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, hipStream_t s);
 
 // gram build: G_aug = Z'Z with Z = [X 1 y]  (n_aug = M + 2), full symmetric, ld = ldg (multiple of 64)

@@ -60,9 +60,8 @@ struct partls_knobs {
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
-    double kkt_tol_tight = 1e-13;// PARTLS_KKT_TOL_TIGHT: the same when the winner's basis is ill-conditioned (see kkt_says_ill_conditioned, api.hip)
-    double kkt_tol = 1e-8;       // PARTLS_KKT_TOL: data-space KKT violation of the winner (units of ||x_m|| ||y||) above which fit(Opt) / fit(BnB) report
-                                 // PARTLS_ERR_ILL_CONDITIONED instead of PARTLS_OK
+    double kkt_tol = 1e-12;      // PARTLS_KKT_TOL: data-space KKT violation of the winner (units of ||x_m|| ||y||) above which fit(Opt) / fit(BnB) report
+                                 // PARTLS_ERR_ILL_CONDITIONED instead of PARTLS_OK (see kkt_says_ill_conditioned, api.hip)
     double cal_wb = 1.0, cal_ws = 1.0;  // PARTLS_CAL_WB / PARTLS_CAL_WS: multipliers of the block / scan weights of the bit-order cost model (experiments)
     int bit_order = 0;           // PARTLS_BIT_ORDER: 0 automatic (calibrate when the sweep is long enough to repay it), "identity" = 1
                                  // (group k on Gray bit k), "calibrate" = 2 (always measure; small problems in the tests)
@@ -161,7 +160,9 @@ double kkt_violation_data(const partls_ctx *c, const std::vector<double> &w, con
 // register kernel) or, without one, a Cholesky factorisation of the host Gram copy.  Brings a Gram-based solution (error ~ cond^2 eps) to the
 // accuracy of a QR-based one (the reference's NNLS) as long as cond^2 eps < 1.  `free_intercept`: the intercept is part
 // of the support even when w[M] == 0.
-partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps = 2);
+// `out` (optional): objective ||Xo w - yo|| and gradient Xo'(yo - Xo w) at the returned w, when the refinement converged (have)
+struct RefineOut { bool have = false; double obj = 0.0; std::vector<double> g; };
+partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps = 2, RefineOut *out = nullptr);
 // regularised augmented Gram entry on the host copy
 double h_reg(const partls_ctx *c, int a, int b);
 partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, int64_t ldX, const void *P, int64_t K, int64_t ldP);

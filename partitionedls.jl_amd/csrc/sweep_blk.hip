@@ -61,6 +61,11 @@ constexpr int split(int T)
 }
 constexpr int rstride(int T) { return (T % 2) ? T : T + 1; }      // odd row stride: 16 lanes x 8 B hit 32 distinct banks
 constexpr int colw(int T) { return 513; }                          // panel column: one slot per thread (16*RS rows + rhs + dummies), odd
+// Small tableaus (T <= MAXT_S tile columns, n <= 160): ONE group of 256 threads owns every tile slot (<= 55 doubles per thread), so a
+// workgroup is 4 waves and a CU holds three of them — three independent chains whose latency chains (panel steps, scans, barriers)
+// interleave on the same SIMDs instead of one chain leaving them idle (BASELINE config 2: n = 128).
+static constexpr int MAXT_S = 10;
+static constexpr int CW_S = 257;                                   // one panel slot per thread of the 256-thread workgroup, odd
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double y = __builtin_amdgcn_rcp(d);
@@ -98,6 +103,20 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane:
 // address is a link-time constant that folds into the ds_* immediates — with a dynamic base the compiler kept ~20 slot
 // addresses in SGPRs and spilled them to VGPR lanes inside the panel steps.  ~100 KB of the CU's 160 KB.
 static constexpr int CWMAX = colw(MAXT);
+template <int CWX, int MAXTX>
+struct LdsImageT {
+    double Z[MB * CWX];
+    double U[2 * (MB + 64)];
+    double Dinv[MB + 64];
+    unsigned long long s_inf[16];
+    unsigned long long s_bas[16];
+    unsigned s_sum[16];
+    int s_veto[2];
+    double s_best[4];
+    unsigned char s_rbit[64];
+    unsigned long long s_vmask[16 * MAXTX];
+    double Pbase[2 * MB * CWX];
+};
 // One struct, so that the order is ours: everything the update and the panel steps address with per-thread offsets (Z, U, Dinv,
 // the masks) sits in the first 64 KB, where base + element offset fits the 16-bit immediate of the ds_* instructions; with Z
 // behind the two panel buffers every operand read of the update loop needed its own v_add for the address.
@@ -116,27 +135,36 @@ struct LdsImage {
     double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
 };
 __shared__ LdsImage lds_image;
+__shared__ LdsImageT<CW_S, MAXT_S> lds_small;              // the 256-thread kernel's image (~51 KB: three workgroups per CU)
 
-template <int T, int H>
+template <int W>
+__device__ __forceinline__ auto *image_of()
+{
+    if constexpr (W == 1) return &lds_small; else return &lds_image;
+}
+
+// W = 2: the tile slots are split between the two halves H = 0 / 1 of a 512-thread workgroup; W = 1: one group of 256 threads owns all
+template <int T, int H, int W = 2>
 struct Half {
-    static constexpr int G = split(T);
+    static constexpr int G = W == 1 ? T : split(T);
     static constexpr int GLO = H ? G : 0;
     static constexpr int GHI = H ? T : G;
     static constexpr int OFF = H ? tri(G) : 0;
     static constexpr int CNT = (H ? nslots(T) - tri(G) : tri(G)) > 0 ? (H ? nslots(T) - tri(G) : tri(G)) : 1;
     static constexpr int XN = GHI;
     static constexpr int RS = rstride(T);
-    static constexpr int CW = colw(T);
+    static constexpr int CW = W == 1 ? CW_S : colw(T);
+    static constexpr int NT = W == 1 ? 256 : THREADS;              // threads of the workgroup
     __device__ static constexpr int idx(int rho, int gam) { return tri(gam) + rho - OFF; }
 };
 
 // ---- tile-column gather ------------------------------------------------------------------------------------------------
 // Element (16 rho + a, 16 KAPPA + b) belongs to column b of the tile, row position a*RS + rho.  Only the pivot columns are
 // gathered, COMPACTED: the j-th pivot of the block (ascending local index) becomes panel column j = popc(pm below it).
-template <int T, int H, int KAPPA, class SA>
+template <int T, int H, int W, int KAPPA, class SA>
 __device__ __forceinline__ void gather_tile(const SA &S, double *P, int a, int b, unsigned pm)
 {
-    using L = Half<T, H>;
+    using L = Half<T, H, W>;
     if constexpr (KAPPA >= L::GLO && KAPPA < L::GHI) {
         if ((pm >> b) & 1u) {
             double *col = P + __builtin_popcount(pm & ((1u << b) - 1u)) * L::CW + a * L::RS;
@@ -152,10 +180,10 @@ __device__ __forceinline__ void gather_tile(const SA &S, double *P, int a, int b
     }
 }
 
-template <int T, int H, int KAPPA, class SA>
+template <int T, int H, int W, int KAPPA, class SA>
 __device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int b, unsigned pm)
 {
-    using L = Half<T, H>;
+    using L = Half<T, H, W>;
     if constexpr (KAPPA >= L::GLO && KAPPA < L::GHI) {
         if ((pm >> b) & 1u) {
             const double *col = P + __builtin_popcount(pm & ((1u << b) - 1u)) * L::CW + a * L::RS;
@@ -241,11 +269,14 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
 
 // NODE: node mode (Alt alpha-steps, BnB bounds: one subproblem per chain, free / zero groups) is a separate instantiation, so
 // that the chain-mode sweep carries neither the node pointers nor the per-thread `free` flag through its loops.
-template <int T, int H, bool NODE>
+template <int T, int H, bool NODE, int W = 2>
 __device__ __forceinline__ void sweep_body(const SweepParams &p)
 {
-    using L = Half<T, H>;
+    using L = Half<T, H, W>;
     constexpr int RS = L::RS, CW = L::CW, RHSPOS = 16 * RS, NW = (T + 3) / 4;      // NW: 64-bit mask words that can be non-empty
+    constexpr int THREADS = L::NT;                                                  // shadows the namespace constant
+    static_assert(W == 2 || RHSPOS < 256, "the 256-thread kernel needs every panel row position (and the rhs row) below 256");
+    auto &lds_image = *image_of<W>();
     const int tid = threadIdx.x, t8 = tid & 255, a = t8 & 15, b = t8 >> 4, lane = tid & 63, wave = tid >> 6;
     const int n = p.n;
     const int nwords = (n + 63) >> 6;
@@ -408,7 +439,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                         asm volatile("" : "+s"(kap));
                         STAMP(12);
                         // ---- 1. gather the pivot columns (compacted) into the LDS panel ------------------------------------
-#define PARTLS_G(i) if constexpr (i < T) { if (__builtin_expect(kap == i, 0)) gather_tile<T, H, i>(S, P, a, b, pm); }
+#define PARTLS_G(i) if constexpr (i < T) { if (__builtin_expect(kap == i, 0)) gather_tile<T, H, W, i>(S, P, a, b, pm); }
                         PARTLS_CASES(PARTLS_G)                 // flat chain of independent ifs: the only form the register allocator keeps spill-free
 #undef PARTLS_G
                         STAMP(13);
@@ -482,7 +513,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                         }
                         STAMP(3);
                         // ---- 4. rows / columns of the pivoted variables come from the final panel ----------------------------
-#define PARTLS_F(i) if constexpr (i < T) { if (__builtin_expect(kap == i, 0)) scatter_tile<T, H, i>(S, P, a, b, pmx); }
+#define PARTLS_F(i) if constexpr (i < T) { if (__builtin_expect(kap == i, 0)) scatter_tile<T, H, W, i>(S, P, a, b, pmx); }
                         PARTLS_CASES(PARTLS_F)
 #undef PARTLS_F
                         if (tid < 16 * T && (tid >> 4) == kappa && ((pmx >> (tid & 15)) & 1u)) {
@@ -567,6 +598,15 @@ __global__ __launch_bounds__(THREADS, 2) void sweep_blk_kernel(SweepParams p)
     else sweep_body<T, 1, NODE>(p);
 }
 
+#ifndef PARTLS_SMALL_OCC
+#define PARTLS_SMALL_OCC(T) ((T) <= 8 ? 3 : 2)          // waves per SIMD = workgroups per CU the allocator is asked to leave room for
+#endif
+template <int T, bool NODE>
+__global__ __launch_bounds__(256, PARTLS_SMALL_OCC(T)) void sweep_small_kernel(SweepParams p)
+{
+    sweep_body<T, 0, NODE, 1>(p);
+}
+
 // Tfull ((n+1)^2) -> tile-cyclic initial state: [slot = tri(gamma) + rho][256 = a + 16 b], then q0[16 T], then the corner
 __global__ void layout_reg_kernel(const double *__restrict__ Tfull, int n, int T, double *__restrict__ out)
 {
@@ -606,9 +646,39 @@ hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, h
 template <int T>
 static hipError_t launch_blk_T(const SweepParams &p, int grid, hipStream_t s)
 {
-    if (p.node_code) hipLaunchKernelGGL((blk::sweep_blk_kernel<T, true>), dim3(grid), dim3(blk::THREADS), 0, s, p);     // ~100 KB of static LDS
-    else hipLaunchKernelGGL((blk::sweep_blk_kernel<T, false>), dim3(grid), dim3(blk::THREADS), 0, s, p);
+    if constexpr (T <= blk::MAXT_S) {                        // small tableau: 256-thread workgroups, several per CU
+        if (p.node_code) hipLaunchKernelGGL((blk::sweep_small_kernel<T, true>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((blk::sweep_small_kernel<T, false>), dim3(grid), dim3(256), 0, s, p);
+    } else {
+        if (p.node_code) hipLaunchKernelGGL((blk::sweep_blk_kernel<T, true>), dim3(grid), dim3(blk::THREADS), 0, s, p);     // ~100 KB of static LDS
+        else hipLaunchKernelGGL((blk::sweep_blk_kernel<T, false>), dim3(grid), dim3(blk::THREADS), 0, s, p);
+    }
     return hipGetLastError();
+}
+
+// chains (workgroups) of the chain-mode sweep a CU runs at the same time: 1 for the 512-thread kernel, the occupancy of the 256-thread one
+template <int T>
+static int concurrency_T()
+{
+    if constexpr (T <= blk::MAXT_S) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&blk::sweep_small_kernel<T, false>), 256, 0) != hipSuccess || n < 1) n = 1;
+        return n;
+    }
+    return 1;
+}
+int sweep_reg_concurrency(int T)
+{
+    switch (T) {
+#ifdef PARTLS_ONLY_T
+        case PARTLS_ONLY_T: return concurrency_T<PARTLS_ONLY_T>();
+#else
+#define PARTLS_L(i) case i + 1: return concurrency_T<i + 1>();
+        PARTLS_CASES(PARTLS_L)
+#undef PARTLS_L
+#endif
+        default: return 1;
+    }
 }
 
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s)

@@ -147,7 +147,7 @@ def test_beyond_the_gram_form_the_call_reports_it(partls, oracle, seed):
                 m, _, rep = partls.fit(alg, X, y, P)
             except partls.PartlsError as e:
                 assert e.status == partls.lowlevel.ERR_ILL_CONDITIONED, e
-                assert partls.default_context().kkt_violation() > 1e-13
+                assert partls.default_context().kkt_violation() > 1e-12
                 reported += 1
                 continue
             # a fit that passed the data-space check is never worse than the oracle's; it may be (slightly) BETTER: at cond > 1e6 the
@@ -155,7 +155,7 @@ def test_beyond_the_gram_form_the_call_reports_it(partls, oracle, seed):
             assert rep.opt <= ref["opt"] * (1 + 1e-9), (noise, alg)
             if abs(rep.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]):
                 np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-6)
-            assert partls.default_context().kkt_violation() <= 1e-13
+            assert partls.default_context().kkt_violation() <= 1e-12
     assert reported >= 4                                   # the two worst levels are certainly out of reach of the Gram form
 
 

@@ -18,17 +18,18 @@ def problem(noise, seed=42, N=2000, D=24, K=4):
 
 
 if __name__ == "__main__":
-    for seed in (42, 43):
+    for seed in (42, 43, 44):
         for noise in [1e-2, 1e-3, 1e-4, 1e-5, 3e-6, 1e-6, 3e-7, 1e-7]:
             X, y, P = problem(noise, seed)
             ref = O.fit_opt(X, y, P)
             ctx = pls.default_context()
-            status = "OK"
-            try:
-                m, _, rep = pls.fit(pls.Opt, X, y, P)
-                opt, bi, a = rep.opt, rep.best_index, m.α
-            except pls.PartlsError as e:
-                status, opt, bi, a = f"status {e.status}", float("nan"), -1, np.full(X.shape[1], np.nan)
             sv = np.linalg.svd(np.hstack([X, np.ones((X.shape[0], 1))]), compute_uv=False)
-            print(f"seed={seed} noise={noise:g} cond(Xo)={sv[0]/sv[-1]:.2e} {status:9s} kkt={ctx.kkt_violation():.2e} vetoes={ctx.vetoes()} "
-                  f"gap={abs(opt-ref['opt'])/max(1,ref['opt']):.2e} best {bi}/{ref['best_index']} max|dalpha|={np.abs(a-ref['alpha']).max():.2e}")
+            for alg in (pls.Opt, pls.BnB):
+                status = "OK"
+                try:
+                    m, _, rep = pls.fit(alg, X, y, P)
+                    opt, a = rep.opt, m.α
+                except pls.PartlsError as e:
+                    status, opt, a = f"status {e.status}", float("nan"), np.full(X.shape[1], np.nan)
+                print(f"seed={seed} noise={noise:g} cond(Xo)={sv[0]/sv[-1]:.2e} {alg.__name__} {status:9s} kkt={ctx.kkt_violation():.2e} min_pivot={ctx.min_pivot():.1e} "
+                      f"vetoes={ctx.vetoes()} gap={(opt-ref['opt'])/max(1,ref['opt']):+.2e} max|dalpha|={np.abs(a-ref['alpha']).max():.2e}")
