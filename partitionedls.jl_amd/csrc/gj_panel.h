@@ -14,9 +14,26 @@ namespace partls {
 
 static constexpr int GJ_MB = 16;              // pivots per block at most
 
-template <int NT>
+// TRI: only the upper triangle of the symmetric tableau is kept (entries (i, c) with c >= i; the rhs is column n): column k of the
+// tableau is T[i][k] for i <= k (strided) and T[k][i] beyond (row k, contiguous).  Halves the bytes of the fused update, which is what
+// bounds the one-workgroup kernel (256 tableaus of (n+1)^2 doubles stream through HBM once per block).
+template <int NT, bool TRI = false>
 __device__ __forceinline__ void gj_panel_load(const double *T, int ld, const int *ks, int m, double *Pn, int tid)
 {
+    if constexpr (TRI) {
+        for (int i = tid; i < ld; i += NT) {
+            double v[GJ_MB];
+#pragma unroll
+            for (int j = 0; j < GJ_MB; ++j) {
+                if (j < m) { const int k = ks[j]; v[j] = __builtin_nontemporal_load(i <= k ? &T[(size_t)i * ld + k] : &T[(size_t)k * ld + i]); }
+                else v[j] = 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < GJ_MB; ++j) if (j < m) Pn[(size_t)j * ld + i] = v[j];
+        }
+        __syncthreads();
+        return;
+    }
     // all m row loads of a thread are issued before the first LDS store: in the cooperative kernel the rows were just rewritten by
     // other XCDs and come from memory (~2 us each) — one exposed latency per block instead of one per pivot row
     for (int i = tid; i < ld; i += NT) {
@@ -116,7 +133,7 @@ __device__ __forceinline__ int gj_panel_eliminate(double *Pn, double *Zn, double
 // reads and FMAs — and one last span of the remaining 1..8 chunks (its own instantiation per length: straight-line code); which pivots of the block were accepted is a wave-uniform bit mask.
 // Tsrc == nullptr: in place (sweep_generic.hip).  Otherwise the rows are read from Tsrc and written to T — the cooperative kernel
 // ping-pongs between two tableau images so that nobody rewrites a row that another workgroup may still be loading.
-template <int NT>
+template <int NT, bool TRI = false>
 __device__ __forceinline__ void gj_apply(double *T, int ld_, int row0_, int row1_, const double *Pn, const double *Zn, const double *dinv,
                                          const int *ks, int m_, int tid, const double *Tsrc = nullptr)
 {
@@ -133,7 +150,9 @@ __device__ __forceinline__ void gj_apply(double *T, int ld_, int row0_, int row1
     const int hs = (((ld + 1) / 2 + 63) / 64) * 64;                         // first half [0, hs), second [hs, ld)
     for (int it = wave; it < nrows * split; it += NWAVES) {
         const int i = row0 + it / split, half = it % split;
-        const int cbeg = half ? hs : 0, cend = (split == 2 && !half) ? (hs < ld ? hs : ld) : ld;
+        int cbeg = half ? hs : 0;
+        const int cend = (split == 2 && !half) ? (hs < ld ? hs : ld) : ld;
+        if constexpr (TRI) { const int lo = i & ~63; if (lo > cbeg) cbeg = lo; if (cbeg >= cend) continue; }   // columns >= i only (whole 64-chunks)
         double *row = T + (size_t)i * ld;
         const double *srow = Tsrc + (size_t)i * ld;
         double fi[GJ_MB];
@@ -185,9 +204,9 @@ __device__ __forceinline__ void gj_apply(double *T, int ld_, int row0_, int row1
     __syncthreads();                                                       // all generic updates of this workgroup are issued
     for (int j = 0; j < m; ++j) {
         const int k = __builtin_amdgcn_readfirstlane(ks[j]);
-        for (int i = row0 + tid; i < row1; i += NT) T[(size_t)i * ld + k] = Pn[j * ld + i];                   // column k
+        for (int i = row0 + tid; i < (TRI ? (k + 1 < row1 ? k + 1 : row1) : row1); i += NT) T[(size_t)i * ld + k] = Pn[j * ld + i];   // column k (TRI: rows <= k)
         if (k >= row0 && k < row1)
-            for (int c = tid; c < ld; c += NT) T[(size_t)k * ld + c] = Pn[j * ld + c];                       // row k
+            for (int c = (TRI ? k : 0) + tid; c < ld; c += NT) T[(size_t)k * ld + c] = Pn[j * ld + c];     // row k (TRI: columns >= k)
     }
     __syncthreads();
 }

@@ -12,7 +12,9 @@
 // group's variables (plus a few neighbours) violate KKT: they are exchanged by block principal pivoting
 // (all violators at once; Kim & Park's finite-termination backup rule), one symmetric rank-1 sweep per variable:
 //        T_ij -= T_ik T_kj / d ,  T_ik = T_ik / |d| ,  T_kk = -1/d        (d = T_kk; the same formula enters and removes).
-// This kernel is the fully general form: full (n+1)^2 tableau per workgroup in global scratch.  With 256 concurrent
+// This kernel is the fully general form: one tableau per workgroup in global scratch, of which only the UPPER TRIANGLE is kept (entries
+// (i, c) with c >= i in an (n+1)^2 image; the rhs is its column n): the tableau is symmetric, and the bytes of the fused update are
+// what bounds this kernel (round 3: 0.84 -> see DESIGN.md §6 M solves/s at D = 340).  With 256 concurrent
 // tableaus of 2 MB (n = 513) the passes over the tableau are HBM-bound, so the violators of a scan are exchanged in BLOCKS of up
 // to 16 pivots (gj_panel.h: panel of the pivot columns eliminated in LDS, then ONE fused rank-m pass over the tableau) instead
 // of one full pass per pivot.  The register-resident production kernel is sweep_blk.hip; all share
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                     const int v = base + tid;
                     bool bad = false;
                     if (v < n) {
-                        const double q = T[(size_t)n * ld + v];
+                        const double q = T[(size_t)v * ld + n];               // the rhs is COLUMN n of the stored upper triangle
                         const int cd = code ? (int)code[v] : 0;
                         const int f = code ? (cd == 2 ? 0 : cd) : sign_of_var(p.mask[v], pat);
                         const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
                 for (int b0 = 0; b0 < nv; b0 += mb) {
                     const int m = (nv - b0 < mb) ? nv - b0 : mb;
                     const int *ks = s_viol + b0;
-                    gj_panel_load<GEN_THREADS>(T, ld, ks, m, Pn, tid);
+                    gj_panel_load<GEN_THREADS, true>(T, ld, ks, m, Pn, tid);
                     const int acc = gj_panel_eliminate<GEN_THREADS>(Pn, Zn, dinv, uj, red, ks, m, ld, s_basic, p.piv_eps, tid);
-                    gj_apply<GEN_THREADS>(T, ld, 0, ld, Pn, Zn, dinv, ks, m, tid);
+                    gj_apply<GEN_THREADS, true>(T, ld, 0, ld, Pn, Zn, dinv, ks, m, tid);
                     if (tid == 0) {
                         for (int j = 0; j < m; ++j) {
                             if (dinv[j] == 0.0) s_blocked[ks[j]] = 1;        // accepted pivots flipped s_basic in the panel
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(GEN_THREADS) void sweep_generic_kernel(SweepParams 
         }
         if (p.node_sol) {
             for (int i = tid; i < n; i += GEN_THREADS)
-                p.node_sol[(size_t)chain * p.node_ld + i] = s_basic[i] ? T[(size_t)n * ld + i] : 0.0;
+                p.node_sol[(size_t)chain * p.node_ld + i] = s_basic[i] ? T[(size_t)i * ld + n] : 0.0;
             if (tid == 0) p.node_obj2[chain] = T[(size_t)n * ld + n];
         }
         __syncthreads();
