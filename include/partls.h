@@ -27,13 +27,14 @@ extern "C" {
 
 typedef enum {
     PARTLS_OK = 0,
-    PARTLS_ERR_BAD_ARG = 1,        /* null pointer, negative size, ld < rows, K too large ...            */
+    PARTLS_ERR_BAD_ARG = 1,        /* null pointer, negative size, ld < rows ...                         */
     PARTLS_ERR_BAD_PARTITION = 2,  /* P has an entry outside {0,1} (PartitionedLS.jl:292 validity clause) */
     PARTLS_ERR_NONFINITE = 3,      /* NaN/Inf in X or y, or a column whose sum of squares overflows fp64    */
     PARTLS_ERR_NO_DEVICE = 4,      /* no HIP device / device index out of range                           */
     PARTLS_ERR_HIP = 5,            /* a HIP runtime call failed (message has the hipError string)         */
     PARTLS_ERR_NOT_CONVERGED = 6,  /* an active-set solve hit its pivot cap                               */
-    PARTLS_ERR_UNSUPPORTED = 7,    /* shape outside what the kernels are built for                        */
+    PARTLS_ERR_UNSUPPORTED = 7,    /* shape outside what the kernels are built for: M > 1022 features, ldX >= 2^30, K > 61 groups,
+                                      K > 39 for the 2^K enumeration of fit(Opt)                                              */
     PARTLS_ERR_STATE = 8,          /* staged calls issued out of order                                    */
     PARTLS_ERR_ILL_CONDITIONED = 9 /* the model's KKT conditions fail when checked against the DATA: X is too ill-conditioned for the
                                       fp64 Gram form (cond(X)^2 * eps >~ 1).  Outputs are filled with the best Gram-form model;

@@ -41,7 +41,8 @@ partls_status check_common(partls_ctx *c, const void *X, int64_t N, int64_t M, i
     if (N < 1 || M < 1 || K < 1) { set_error("need N, M, K >= 1 (got %lld, %lld, %lld)", (long long)N, (long long)M, (long long)K); return PARTLS_ERR_BAD_ARG; }
     if (ldX < N || ldP < M) { set_error("leading dimension smaller than the row count"); return PARTLS_ERR_BAD_ARG; }
     if (ldX >= ((int64_t)1 << 30)) { set_error("ldX = %lld: this build supports leading dimensions below 2^30 rows", (long long)ldX); return PARTLS_ERR_UNSUPPORTED; }
-    if (K > 39) { set_error("K = %lld groups: 2^(K+1) sign patterns is out of range (K <= 39)", (long long)K); return PARTLS_ERR_UNSUPPORTED; }
+    // group masks are 64-bit words with the intercept's group on bit K; the ENUMERATION of Opt is limited further (see opt_range_ok)
+    if (K > 61) { set_error("K = %lld groups: this build supports K <= 61 (Alt, BnB, predict) and K <= 39 for the enumeration of fit(Opt)", (long long)K); return PARTLS_ERR_UNSUPPORTED; }
     if (M + 1 > 1023) { set_error("M = %lld features: this build supports M <= 1022", (long long)M); return PARTLS_ERR_UNSUPPORTED; }
     return PARTLS_OK;
 }
@@ -159,6 +160,14 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (!(c->tol > 0.0)) c->tol = 1e-300;
     c->prepared = true;
     return PARTLS_OK;
+}
+
+// fit(Opt) enumerates 2^K' patterns: beyond K' = 40 that is out of range (and of the tables of the visiting order)
+static bool opt_range_ok(const partls_ctx *c, const char *who)
+{
+    if (c->kbits <= 40) return true;
+    set_error("%s: %d sign bits: the enumeration of 2^(K+1) patterns is out of range (K <= 39); fit(Alt) and fit(BnB) take up to 61 groups", who, c->kbits);
+    return false;
 }
 
 static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
@@ -732,7 +741,7 @@ partls_status partls_opt_prepare(partls_ctx *c, const double *X, int64_t N, int6
     return ctx_prepare(c, X, N, M, ldX, y, x_on_device, P, K, ldP, eta, (flags & PARTLS_OPT_FAITHFUL_INTERCEPT) != 0, flags);
 }
 
-int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared) ? ((int64_t)1 << c->kbits) : 0; }
+int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared && c->kbits <= 40) ? ((int64_t)1 << c->kbits) : 0; }
 
 // Which group sits on which bit of the Gray index.  Bit b flips in 2^-(b+1) of all transitions and a flip exchanges roughly the
 // variables of its group that carry signal, so the cheap groups belong on the fast bits: on C3 the reference's order (group k on
@@ -849,6 +858,7 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
                                double *all_opt, int64_t *n_unconverged)
 {
     if (!c || !c->prepared) { set_error("partls_opt_sweep: context not prepared"); return PARTLS_ERR_STATE; }
+    if (!opt_range_ok(c, "partls_opt_sweep")) return PARTLS_ERR_UNSUPPORTED;
     const int64_t npat = (int64_t)1 << c->kbits;
     if (g_end < 0) g_end = npat;
     if (g_begin < 0 || g_begin > g_end || g_end > npat) { set_error("bad Gray-index range [%lld,%lld)", (long long)g_begin, (long long)g_end); return PARTLS_ERR_BAD_ARG; }
@@ -1243,6 +1253,7 @@ partls_status partls_opt_bit_order(partls_ctx *c, int64_t *gbit, double *flip_co
 {
     if (!c || !c->prepared) { set_error("partls_opt_bit_order: context not prepared"); return PARTLS_ERR_STATE; }
     if (!gbit) { set_error("partls_opt_bit_order: gbit is NULL"); return PARTLS_ERR_BAD_ARG; }
+    if (!opt_range_ok(c, "partls_opt_bit_order")) return PARTLS_ERR_UNSUPPORTED;
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     if (!c->order_ready) {
         partls_status st = calibrate_bit_order(c);

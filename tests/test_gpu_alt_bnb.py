@@ -186,3 +186,43 @@ def test_bnb_search_node_cap(partls):
     mu_cap, _, _, n_cap = ctx.bnb_search(5)
     ctx.close()
     assert 5 <= n_cap <= 5 + 1024 and n_cap <= n_full and (mu_cap >= mu_full)
+
+
+def _many_groups_problem(K=45, seed=31):
+    """K groups (> 39: beyond the enumeration of Opt, which needs 2^K solves): 5 groups of four features with mixed true signs — the
+    only ones BnB can branch on — and K - 5 singletons"""
+    rng = np.random.default_rng(seed)
+    D = 20 + (K - 5)
+    P = np.zeros((D, K), dtype=np.int64)
+    for g in range(5):
+        P[4 * g:4 * g + 4, g] = 1
+    for j in range(K - 5):
+        P[20 + j, 5 + j] = 1
+    N = 600
+    X = rng.standard_normal((N, D))
+    y = X @ rng.standard_normal(D) + 0.4 + 0.1 * rng.standard_normal(N)
+    return X, y, P
+
+
+def test_alt_and_bnb_take_more_groups_than_opt_can_enumerate(partls, oracle):
+    """The reference has no limit on the number of groups; Opt's 2^K enumeration stops at K = 39 here, Alt and BnB (64-bit group masks)
+    at K = 61 — with a clear status for fit(Opt) beyond its range."""
+    X, y, P = _many_groups_problem()
+    K = P.shape[1]
+    rng = np.random.default_rng(3)
+    a0 = rng.random(X.shape[1] + 1); b0 = (rng.random(K + 1) - 0.5) * 10
+    ref = oracle.fit_alt(X, y, P, a0, b0, T=30)
+    m, _, rep = partls.fit(partls.Alt, X, y, P, alpha0=a0, beta0=b0, T=30)
+    assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(partls.predict(m, X), oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"]), atol=1e-6)
+    refb = oracle.fit_bnb(X, y, P)
+    mb, _, repb = partls.fit(partls.BnB, X, y, P)
+    assert abs(repb.opt - refb["opt"]) <= 1e-9 * max(1.0, refb["opt"]) and repb.nopen >= 3
+    np.testing.assert_allclose(partls.predict(mb, X), oracle.predict(X, P, refb["alpha"], refb["beta"], refb["t"]), atol=1e-7)
+    with pytest.raises(partls.PartlsError) as ei:
+        partls.fit(partls.Opt, X, y, P)
+    assert ei.value.status == partls.lowlevel.ERR_UNSUPPORTED and "K <= 39" in str(ei.value)
+    Pbig = np.zeros((X.shape[1], 62), dtype=np.int64); Pbig[np.arange(X.shape[1]), np.arange(X.shape[1]) % 62] = 1
+    with pytest.raises(partls.PartlsError) as ei:
+        partls.fit(partls.BnB, X, y, Pbig)
+    assert ei.value.status == partls.lowlevel.ERR_UNSUPPORTED
