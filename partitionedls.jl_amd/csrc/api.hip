@@ -659,7 +659,7 @@ int partls_device_count(void)
 }
 
 partls_status partls_create(int device, partls_ctx **out)
-{
+try {
     if (!out) { set_error("partls_create: out is NULL"); return PARTLS_ERR_BAD_ARG; }
     *out = nullptr;
     int n = partls_device_count();
@@ -705,6 +705,8 @@ partls_status partls_create(int device, partls_ctx **out)
     *out = c;
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 void partls_destroy(partls_ctx *c)
 {
@@ -737,9 +739,11 @@ void partls_destroy(partls_ctx *c)
 
 partls_status partls_opt_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                                  int x_on_device, const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags)
-{
+try {
     return ctx_prepare(c, X, N, M, ldX, y, x_on_device, P, K, ldP, eta, (flags & PARTLS_OPT_FAITHFUL_INTERCEPT) != 0, flags);
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 int64_t partls_opt_num_patterns(const partls_ctx *c) { return (c && c->prepared && c->kbits <= 40) ? ((int64_t)1 << c->kbits) : 0; }
 
@@ -856,7 +860,7 @@ static int64_t reference_pattern(const partls_ctx *c, int64_t q)
 
 partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, double *best_obj, int64_t *best_pattern,
                                double *all_opt, int64_t *n_unconverged)
-{
+try {
     if (!c || !c->prepared) { set_error("partls_opt_sweep: context not prepared"); return PARTLS_ERR_STATE; }
     if (!opt_range_ok(c, "partls_opt_sweep")) return PARTLS_ERR_UNSUPPORTED;
     const int64_t npat = (int64_t)1 << c->kbits;
@@ -1006,10 +1010,12 @@ partls_status partls_opt_sweep(partls_ctx *c, int64_t g_begin, int64_t g_end, do
     if (n_unconverged) *n_unconverged = (int64_t)cnt[0];
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, double *beta, double *t, double *opt,
                                 int64_t *best_index)
-{
+try {
     if (!c || !c->prepared) { set_error("partls_opt_finish: context not prepared"); return PARTLS_ERR_STATE; }
     if (!alpha || !beta || !t || !opt) { set_error("partls_opt_finish: NULL output"); return PARTLS_ERR_BAD_ARG; }
     if (pattern < 0 || pattern >= ((int64_t)1 << (c->K + 1))) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
@@ -1090,9 +1096,11 @@ partls_status partls_opt_finish(partls_ctx *c, int64_t pattern, double *alpha, d
     }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alpha, double *optval)
-{
+try {
     if (!c || !c->prepared) { set_error("partls_opt_pattern: context not prepared"); return PARTLS_ERR_STATE; }
     if (!c->faithful) { set_error("partls_opt_pattern needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (pattern < 0 || pattern >= ((int64_t)1 << c->kbits)) { set_error("pattern out of range"); return PARTLS_ERR_BAD_ARG; }
@@ -1116,11 +1124,13 @@ partls_status partls_opt_pattern(partls_ctx *c, int64_t pattern, double *raw_alp
     if (unconv) { set_error("pattern solve hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_fit_opt(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                              const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
                              double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt)
-{
+try {
     if (all_opt) flags |= PARTLS_OPT_FAITHFUL_INTERCEPT;
     partls_status st = partls_opt_prepare(c, X, N, M, ldX, y, 0, P, K, ldP, eta, flags);
     if (st != PARTLS_OK) return st;
@@ -1133,6 +1143,8 @@ partls_status partls_fit_opt(partls_ctx *c, const double *X, int64_t N, int64_t 
     if (unconv) { set_error("%lld subproblems hit the pivot cap", (long long)unconv); return PARTLS_ERR_NOT_CONVERGED; }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 // predict: w_m = sum_k P[m,k] alpha_m beta_k on the host (M*K flops), yhat = X w + t on the device (one pass over X)
 static partls_status predict_common(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, int x_on_device,
@@ -1175,18 +1187,22 @@ static partls_status predict_common(partls_ctx *c, const double *X, int64_t N, i
 
 partls_status partls_predict(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const int64_t *P, int64_t K,
                              int64_t ldP, const double *alpha, const double *beta, double t, double *yhat)
-{
+try {
     return predict_common(c, X, N, M, ldX, 0, P, K, ldP, alpha, beta, t, yhat);
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_predict_device(partls_ctx *c, const double *dX, int64_t N, int64_t M, int64_t ldX, const int64_t *P,
                                     int64_t K, int64_t ldP, const double *alpha, const double *beta, double t, double *dyhat)
-{
+try {
     return predict_common(c, dX, N, M, ldX, 1, P, K, ldP, alpha, beta, t, dyhat);
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_synth_truth(uint64_t seed, int64_t D, int64_t K, int64_t *P, double *wstar)
-{
+try {
     if (D < 1 || K < 1 || K > D) { set_error("partls_synth_truth: bad D/K"); return PARTLS_ERR_BAD_ARG; }
     std::vector<int64_t> grp((size_t)D);
     int64_t j = 0;
@@ -1208,9 +1224,11 @@ partls_status partls_synth_truth(uint64_t seed, int64_t D, int64_t K, int64_t *P
         }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_synth_device(partls_ctx *c, uint64_t seed, int64_t N, int64_t D, const double *wstar, double *dX, double *dy)
-{
+try {
     if (!c || !wstar || !dX || !dy || N < 1 || D < 1) { set_error("partls_synth_device: bad argument"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     PARTLS_HIP_CHECK(c->wdev.ensure((size_t)D * sizeof(double)));
@@ -1219,38 +1237,48 @@ partls_status partls_synth_device(partls_ctx *c, uint64_t seed, int64_t N, int64
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_timing(const partls_ctx *c, partls_timer which, double *ms)
-{
+try {
     if (!c || !ms || (int)which < 0 || (int)which >= PARTLS_T_COUNT) { set_error("partls_get_timing: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *ms = c->ms[(int)which];
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_pivots(const partls_ctx *c, int64_t *pivots)
-{
+try {
     if (!c || !pivots) { set_error("partls_get_pivots: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *pivots = (int64_t)c->last_pivots;
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_kkt_violation(const partls_ctx *c, double *violation, double *min_pivot)
-{
+try {
     if (!c || !violation) { set_error("partls_get_kkt_violation: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *violation = c->last_kkt;
     if (min_pivot) *min_pivot = c->last_min_loo;
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_vetoes(const partls_ctx *c, int64_t *vetoes)
-{
+try {
     if (!c || !vetoes) { set_error("partls_get_vetoes: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *vetoes = (int64_t)c->last_vetoes;
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_opt_bit_order(partls_ctx *c, int64_t *gbit, double *flip_cost)
-{
+try {
     if (!c || !c->prepared) { set_error("partls_opt_bit_order: context not prepared"); return PARTLS_ERR_STATE; }
     if (!gbit) { set_error("partls_opt_bit_order: gbit is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (!opt_range_ok(c, "partls_opt_bit_order")) return PARTLS_ERR_UNSUPPORTED;
@@ -1265,14 +1293,18 @@ partls_status partls_opt_bit_order(partls_ctx *c, int64_t *gbit, double *flip_co
     }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_gram(const partls_ctx *c, double *G_aug)
-{
+try {
     if (!c || !c->prepared || !G_aug) { set_error("partls_get_gram: context not prepared"); return PARTLS_ERR_STATE; }
     const int na = (int)c->M + 2;
     for (int j = 0; j < na; ++j)
         for (int i = 0; i < na; ++i) G_aug[(size_t)i + (size_t)j * na] = h_reg(c, i, j);
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 }  // extern "C"

@@ -7,6 +7,7 @@
 // with two RCCL all-reduces (ncclMin on the objective, ncclMin on the index masked to the minimisers): 24 + 8 bytes over xGMI,
 // latency-bound.  RCCL is loaded on first use (573 MB on disk: a single-GPU fit never pays for it).
 #include "ctx.h"
+#include <new>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <condition_variable>
@@ -186,8 +187,13 @@ void rank_main(partls_multi *mc, int r, const FitArgs &a)
             key = order_key(gbit, c->kbits);
             const int64_t g0 = (int64_t)(((__int128)r * npat) / R), g1 = (int64_t)(((__int128)(r + 1) * npat) / R);
             double *ao = nullptr;
-            if (a.all_opt) { mc->all_opt[(size_t)r].resize((size_t)((int64_t)1 << (a.K + 1))); ao = mc->all_opt[(size_t)r].data(); }
-            st = partls_opt_sweep(c, g0, g1, &bobj, &bpat, ao, &unconv);
+            bool have_buf = true;
+            if (a.all_opt) {                                   // this rank's image of all_opt (NaN outside its shard), merged by the caller
+                try { mc->all_opt[(size_t)r].resize((size_t)((int64_t)1 << (a.K + 1))); ao = mc->all_opt[(size_t)r].data(); }
+                catch (...) { have_buf = false; }               // no exception may leave a rank's thread, let alone the C ABI
+            }
+            if (have_buf) st = partls_opt_sweep(c, g0, g1, &bobj, &bpat, ao, &unconv);
+            else { set_error("out of host memory for the per-rank image of all_opt (2^(K+1) doubles per rank)"); st = PARTLS_ERR_BAD_ARG; }
         }
     }
     if (st != PARTLS_OK) fail(mc, r, st);
@@ -216,7 +222,7 @@ void rank_main(partls_multi *mc, int r, const FitArgs &a)
 extern "C" {
 
 partls_status partls_multi_create(const int *devices, int ndev, partls_multi **out)
-{
+try {
     if (!out) { set_error("partls_multi_create: out is NULL"); return PARTLS_ERR_BAD_ARG; }
     *out = nullptr;
     const int visible = partls_device_count();
@@ -267,6 +273,8 @@ partls_status partls_multi_create(const int *devices, int ndev, partls_multi **o
     *out = mc;
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 void partls_multi_destroy(partls_multi *mc)
 {
@@ -289,16 +297,18 @@ int partls_multi_uses_rccl(const partls_multi *mc) { return (mc && mc->use_rccl)
 partls_ctx *partls_multi_context(partls_multi *mc, int rank) { return (mc && rank >= 0 && rank < mc->ndev) ? mc->ctx[(size_t)rank] : nullptr; }
 
 partls_status partls_multi_get_timing(const partls_multi *mc, int rank, int which, double *ms)
-{
+try {
     if (!mc || !ms || rank < 0 || rank >= mc->ndev || which < 0 || which >= PARTLS_T_COUNT) { set_error("partls_multi_get_timing: bad argument"); return PARTLS_ERR_BAD_ARG; }
     *ms = mc->t_ms[(size_t)rank][(size_t)which];
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_fit_opt_multi(partls_multi *mc, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                                    const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
                                    double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt)
-{
+try {
     if (!mc) { set_error("partls_fit_opt_multi: handle is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (!alpha || !beta || !t || !opt) { set_error("partls_fit_opt_multi: NULL output"); return PARTLS_ERR_BAD_ARG; }
     if (all_opt) flags |= PARTLS_OPT_FAITHFUL_INTERCEPT;
@@ -329,5 +339,7 @@ partls_status partls_fit_opt_multi(partls_multi *mc, const double *X, int64_t N,
     if (unconv) { set_error("%lld subproblems hit the pivot cap", (long long)unconv); return PARTLS_ERR_NOT_CONVERGED; }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 }  // extern "C"

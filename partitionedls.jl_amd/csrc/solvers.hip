@@ -12,6 +12,7 @@
 //     incumbent prunes (BnB.jl:102); the node count depends on the search order and is not a parity quantity.  A feature of
 //     several groups collects one constraint per branched group (BnB.jl:120-121): opposite ones force it to 0.
 #include "ctx.h"
+#include <new>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -175,15 +176,17 @@ partls_status partls_fit_alt(partls_ctx *c, const double *X, int64_t N, int64_t 
                              const int64_t *P, int64_t K, int64_t ldP, double eta, double eps, int64_t T,
                              const double *alpha0, const double *beta0,
                              double *alpha, double *beta, double *t, double *opt, int64_t *iters)
-{
+try {
     partls_status st = ctx_prepare(c, X, N, M, ldX, y, 0, P, K, ldP, eta, /*faithful=*/true, 0);
     if (st != PARTLS_OK) return st;
     return partls_alt_prepared(c, eps, T, alpha0, beta0, alpha, beta, t, opt, iters);
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const double *alpha0, const double *beta0,
                                   double *alpha, double *beta, double *t, double *opt, int64_t *iters)
-{
+try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_alt_prepared: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (!alpha0 || !beta0 || !alpha || !beta || !t || !opt) { set_error("partls_fit_alt: NULL argument"); return PARTLS_ERR_BAD_ARG; }
     if (!(eps > 0.0) || T < 1) { set_error("partls_fit_alt: need eps > 0 and T >= 1 (PartitionedLS.jl:294-295)"); return PARTLS_ERR_BAD_ARG; }
@@ -284,15 +287,19 @@ partls_status partls_alt_prepared(partls_ctx *c, double eps, int64_t T, const do
     if (unconv_total) { set_error("partls_fit_alt: an alpha-step hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_fit_bnb(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                              const int64_t *P, int64_t K, int64_t ldP, double eta,
                              double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
-{
+try {
     partls_status st = ctx_prepare(c, X, N, M, ldX, y, 0, P, K, ldP, eta, /*faithful=*/true, 0);
     if (st != PARTLS_OK) return st;
     return partls_bnb_prepared(c, alpha, beta, t, opt, nopen);
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 // ---- BnB primitives (shared by the single-rank driver below and the rank-sharded search of partitionedls.jl_amd/dist.py) -------
 // A node is (pat, free): group k is branched iff bit k of `free` is clear, and then constrained to alpha_pk >= 0 (bit k of pat
@@ -300,7 +307,7 @@ partls_status partls_fit_bnb(partls_ctx *c, const double *X, int64_t N, int64_t 
 // (BnB.jl:69-92 on the device) and branch[i] = argmax_k nu_k (BnB.jl:107,117), or -1 when all nu_k == 0, i.e. the relaxed
 // solution is feasible for the original problem and lb[i] is its value (BnB.jl:109-115).
 partls_status partls_bnb_bound(partls_ctx *c, int64_t count, const uint64_t *pat, const uint64_t *free_, double *lb, int32_t *branch)
-{
+try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (count < 0 || (count > 0 && (!pat || !free_ || !lb || !branch))) { set_error("partls_bnb_bound: bad argument"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
@@ -351,10 +358,12 @@ partls_status partls_bnb_bound(partls_ctx *c, int64_t count, const uint64_t *pat
     if (unconv) { set_error("partls_bnb_bound: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 // The model of one (feasible) node: re-solve, data-space refinement, BnB.jl:36-39 normalisation, objective from the data.
 partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, double *alpha, double *beta, double *t, double *opt)
-{
+try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_leaf: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (!alpha || !beta || !t || !opt) { set_error("partls_bnb_leaf: NULL argument"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
@@ -399,6 +408,8 @@ partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, doubl
     }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 // fit_BnB (BnB.jl:94-132) as a best-first search: frontier ordered by the parent's bound, nodes bounded in device batches, the
 // incumbent prunes (BnB.jl:102).  Same optimum as the reference's depth-first recursion; the node count is not.  On the register
@@ -406,7 +417,7 @@ partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, doubl
 // constraint set plus one group (BnB.jl:120-124), here it also inherits the parent's basis.
 // max_nodes > 0 (measurement): stop after that many bounded nodes and report the incumbent so far (*mu = inf when there is none).
 partls_status partls_bnb_search(partls_ctx *c, int64_t max_nodes, double *mu_out, uint64_t *pat_out, uint64_t *free_out, int64_t *nodes_out)
-{
+try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_search: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (!mu_out || !pat_out || !free_out) { set_error("partls_bnb_search: NULL output"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
@@ -478,9 +489,11 @@ partls_status partls_bnb_search(partls_ctx *c, int64_t max_nodes, double *mu_out
     if (unconv_total) { set_error("partls_bnb_search: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
     return PARTLS_OK;
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
-{
+try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_prepared: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (!alpha || !beta || !t || !opt) { set_error("partls_fit_bnb: NULL argument"); return PARTLS_ERR_BAD_ARG; }
     double mu = INFINITY;
@@ -492,5 +505,7 @@ partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, do
     if (nopen) *nopen = bounded;
     return partls_bnb_leaf(c, best_pat, best_free, alpha, beta, t, opt);
 }
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 }  // extern "C"
