@@ -68,12 +68,15 @@ partls_status partls_fit_opt(partls_ctx *ctx, const double *X, int64_t N, int64_
                              double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt);
 
 /* ---- fit(Opt) on several GPUs of one node, inside the library  — the loop Opt.jl:85-94 has no loop-carried state ---------
- * One process, one host thread and one context per device.  Every device builds the Gram products from X (replicated upload),
- * sweeps the Gray-index range [r * 2^K' / R, (r+1) * 2^K' / R) of the pattern space, and the global lexicographic minimum
+ * One process, one host thread and one context per device.  Device r uploads rows [r N / R, (r+1) N / R) of X and y (1 / R of the PCIe
+ * traffic each) and builds the Gram products of its block; their sum — ncclAllReduce(ncclSum) on (M+2)^2 doubles over xGMI — is the
+ * problem every device then prepares.  Device r sweeps the Gray-index range [r * 2^K' / R, (r+1) * 2^K' / R) of the pattern space,
+ * and the global lexicographic minimum
  * (objective, reference pattern index) — argmin's first-index rule, Opt.jl:96 — is taken with two RCCL all-reduces over xGMI:
  * ncclMin on the objective, then ncclMin on the index masked to the minimisers (RCCL has no MINLOC).  The key of the
  * visiting order rides in the first all-reduce; ranks that disagree on it fail with PARTLS_ERR_STATE instead of combining
- * shards that do not partition the pattern space.  The winner is re-solved on the first device.
+ * shards that do not partition the pattern space.  The winner is re-solved on the first device; the passes over the data it needs
+ * (refinement, objective, KKT check) run on every device's row block and are summed in rank order.
  *   devices[ndev]: HIP device indices (devices == NULL: devices 0 .. ndev-1; ndev == 0: every visible device).
  *   A list that names one device more than once (rehearsal of the R-rank control flow on a one-GPU box) cannot form an RCCL
  *   communicator: its reduction runs through the host instead; everything else is the same code.

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <algorithm>
 #include <numeric>
 #include <new>
@@ -78,6 +79,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (!y) { set_error("y is NULL"); return PARTLS_ERR_BAD_ARG; }
     if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
     c->prepared = false;
+    c->peers.clear();                              // a row-sharded fit sets them again after every rank has prepared its block
     c->near_for = -1; c->near_pat.clear();
     c->sweep_vetoes = 0;
     c->coop_state_valid = false;
@@ -106,6 +108,8 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     PARTLS_HIP_CHECK(launch_gram(c->dX, N, M, c->ldX, c->dy, c->slab.as<double>(), c->chunks, c->ldg, c->knobs.gram_S, c->knobs.gram_cr,
                                  c->G.as<double>(), c->stream));
     t_end(c, PARTLS_T_GRAM);
+    // rows of X sharded over several devices: the Gram products of the blocks are summed here (partls_fit_opt_multi, multi.hip)
+    if (c->gram_hook) { st = c->gram_hook(c); if (st != PARTLS_OK) return st; }
 
     // tableau variables, grouped by partition (stable sort on the lowest group a variable belongs to) so that the
     // variables one Gray-code flip touches sit in as few 16-wide tile columns as possible
@@ -319,62 +323,84 @@ void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double
     }
 }
 
+// One pass over the DATA of the prepared problem — all of it: this context's rows and, when the rows of X are sharded over several
+// devices (partls_fit_opt_multi), those its peers hold:  *obj2 = sum_i (Xo w - y)_i^2  (without the eta rows) and, optionally,
+// g = Xo'(y - Xo w) over [features, intercept].  The kernels of every device are queued first (one host thread drives them all), the
+// caller's `overlap` work runs on the host meanwhile, then the partial sums are added in a fixed order (context, then peers; slices in
+// order): run-to-run reproducible.
+partls_status data_pass(partls_ctx *c, const std::vector<double> &w, bool want_obj, bool want_grad, double *obj2, std::vector<double> *g,
+                        const std::function<void()> &overlap)
+{
+    const int64_t M = c->M;
+    const int nb = 1024;
+    std::vector<partls_ctx *> cs{c};
+    cs.insert(cs.end(), c->peers.begin(), c->peers.end());
+    for (partls_ctx *q : cs) {
+        PARTLS_HIP_CHECK(hipSetDevice(q->device));
+        const int64_t N = q->N;
+        const int xr = xtr_slices(N);
+        PARTLS_HIP_CHECK(q->wdev.ensure((size_t)(M + 1) * sizeof(double)));
+        PARTLS_HIP_CHECK(hipMemcpyAsync(q->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, q->stream));
+        double *yhat = nullptr;
+        if (want_obj) { PARTLS_HIP_CHECK(q->partial.ensure(nb * sizeof(double))); q->hPart.resize((size_t)nb); }
+        if (want_grad) {
+            PARTLS_HIP_CHECK(q->yhatD.ensure((size_t)N * sizeof(double)));
+            PARTLS_HIP_CHECK(q->gD.ensure((size_t)xr * (M + 1) * sizeof(double)));
+            yhat = q->yhatD.as<double>();
+            q->hGpart.resize((size_t)xr * (M + 1));
+        }
+        PARTLS_HIP_CHECK(launch_residual(q->dX, N, M, q->ldX, want_obj ? q->dy : nullptr, q->wdev.as<double>(), w[(size_t)M],
+                                         want_obj ? q->partial.as<double>() : nullptr, nb, yhat, q->stream));
+        if (want_grad) {
+            PARTLS_HIP_CHECK(launch_xtr(q->dX, N, M, q->ldX, q->dy, yhat, q->gD.as<double>(), q->stream));
+            PARTLS_HIP_CHECK(hipMemcpyAsync(q->hGpart.data(), q->gD.p, q->hGpart.size() * sizeof(double), hipMemcpyDeviceToHost, q->stream));
+        }
+        if (want_obj) PARTLS_HIP_CHECK(hipMemcpyAsync(q->hPart.data(), q->partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, q->stream));
+    }
+    if (overlap) overlap();
+    double s = 0.0;
+    if (want_grad) g->assign((size_t)M + 1, 0.0);
+    for (partls_ctx *q : cs) {
+        PARTLS_HIP_CHECK(hipSetDevice(q->device));
+        PARTLS_HIP_CHECK(hipStreamSynchronize(q->stream));
+        if (want_obj) for (int b = 0; b < nb; ++b) s += q->hPart[(size_t)b];
+        if (want_grad) {
+            const int xr = xtr_slices(q->N);
+            for (int64_t m = 0; m <= M; ++m) {
+                double sg = 0.0;
+                for (int r = 0; r < xr; ++r) sg += q->hGpart[(size_t)r * (M + 1) + m];
+                (*g)[(size_t)m] += sg;
+            }
+        }
+    }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    if (want_obj) *obj2 = s;
+    return PARTLS_OK;
+}
+
+// the eta rows of regularizeProblem (PartitionedLS.jl:108-123): sqrt(eta) * sum_{m in group k} w_m  ->  their share of obj^2 and of g
+static void eta_terms(const partls_ctx *c, const std::vector<double> &w, double *obj2, std::vector<double> *grad)
+{
+    if (c->eta == 0.0) return;
+    const int64_t M = c->M;
+    for (int64_t k = 0; k <= c->K; ++k) {
+        double gs = 0.0;
+        for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) gs += w[(size_t)m];
+        if (obj2) *obj2 += c->eta * gs * gs;
+        if (grad) for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) (*grad)[(size_t)m] -= c->eta * gs;
+    }
+}
+
 partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt, std::vector<double> *grad)
 {
-    const int64_t M = c->M, N = c->N;
-    const int nb = 1024;
-    PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
-    PARTLS_HIP_CHECK(c->partial.ensure(nb * sizeof(double)));
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    double *yhat = nullptr;
-    const int xr = xtr_slices(N);
-    std::vector<double> gpart;
-    if (grad) {                                          // the same pass leaves Xo w; a second one gives Xo'(y - Xo w)
-        PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
-        PARTLS_HIP_CHECK(c->gD.ensure((size_t)xr * (M + 1) * sizeof(double)));
-        yhat = c->yhatD.as<double>();
-        gpart.resize((size_t)xr * (M + 1));
-    }
-    PARTLS_HIP_CHECK(launch_residual(c->dX, N, M, c->ldX, c->dy, c->wdev.as<double>(), w[(size_t)M],
-                                     c->partial.as<double>(), nb, yhat, c->stream));
-    if (grad) {
-        PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, yhat, c->gD.as<double>(), c->stream));
-        PARTLS_HIP_CHECK(hipMemcpyAsync(gpart.data(), c->gD.p, gpart.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
-    std::vector<double> part((size_t)nb);
-    PARTLS_HIP_CHECK(hipMemcpyAsync(part.data(), c->partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[(size_t)b];
-    if (grad) {
-        grad->assign((size_t)M + 1, 0.0);
-        for (int64_t m = 0; m <= M; ++m) {
-            double sg = 0.0;
-            for (int r = 0; r < xr; ++r) sg += gpart[(size_t)r * (M + 1) + m];
-            (*grad)[(size_t)m] = sg;
-        }
-    }
-    if (c->eta != 0.0) {
-        for (int64_t k = 0; k <= c->K; ++k) {           // the K' regularisation rows: sqrt(eta) * sum_{m in group k} w_m
-            double g = 0.0;
-            for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) g += w[(size_t)m];
-            s += c->eta * g * g;
-            if (grad) for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) (*grad)[(size_t)m] -= c->eta * g;
-        }
-    }
+    partls_status st = data_pass(c, w, true, grad != nullptr, &s, grad, {});
+    if (st != PARTLS_OK) return st;
+    eta_terms(c, w, &s, grad);
     *opt = std::sqrt(s);
     return PARTLS_OK;
 }
 
-// KKT conditions of ONE sign-constrained subproblem in DATA space (no Gram entry involved besides the column norms that scale the
-// test): g = Xo'(yo - Xo w) is minus the gradient, so at the optimum of  min ||Xo w - yo||  s.t.  f_m w_m >= 0
-//     w_m != 0 or m free :  g_m = 0                (stationarity on the passive set)
-//     w_m == 0, f_m != 0 :  f_m g_m <= 0           (no descent direction inside the orthant)
-//     f_m w_m >= 0.
-// Returns the largest violation in units of ||x_m|| ||y||, i.e. comparable with the sweep's own tolerance (1e-11 on the
-// unit-diagonal scale).  What it catches that the tableau cannot: a column the leave-one-out rule rejected as dependent although it
-// carries information below the resolution of the fp64 Gram (cond(X~) >~ 1e6) — the reference's QR-based NNLS (Opt.jl:89) takes it.
-// `code[m]`: +1 / -1 / 0 (forced to zero) / 2 (free) for m in [features, intercept].
 // When is a data-space KKT violation evidence that the Gram form has lost the problem?  Measured on problems of cond(Xo) 7e2 .. 8e7
 // (tools/illcond_check.py, three seeds, Opt and BnB): every fit that equals the oracle's has a violation <= 3e-15 (the rounding of the
 // data passes: eps * sqrt(N) * ||r|| / ||y||), every fit that differs from it has one >= 1.2e-11 — the residual gradient along a nearly
@@ -413,7 +439,7 @@ double kkt_violation_data(const partls_ctx *c, const std::vector<double> &w, con
 
 partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps, RefineOut *out)
 {
-    const int64_t M = c->M, N = c->N;
+    const int64_t M = c->M;
     if (out) out->have = false;
     std::vector<int> sup;
     for (int m = 0; m <= (int)M; ++m)
@@ -455,18 +481,12 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     }
     const bool tab_full = c->tab_full;
     const int tld = c->n + 1;
-    PARTLS_HIP_CHECK(c->wdev.ensure((size_t)(M + 1) * sizeof(double)));
-    PARTLS_HIP_CHECK(c->yhatD.ensure((size_t)N * sizeof(double)));
-    const int xr = xtr_slices(N);
-    PARTLS_HIP_CHECK(c->gD.ensure((size_t)xr * (M + 1) * sizeof(double)));
-    std::vector<double> gpart((size_t)xr * (M + 1));
     std::vector<double> g((size_t)M + 1), d((size_t)p);
     // `out`: the pass that finds the correction negligible has already computed the squared residual and Xo'(yo - Xo w) one tiny step
     // before the final w; both are carried over exactly (obj^2 -= 2 g'delta, g -= B delta with the host Gram copy) instead of being
     // recomputed by two more passes over X
-    const int nbp = 1024;
-    std::vector<double> part, delta;
-    if (out) { PARTLS_HIP_CHECK(c->partial.ensure(nbp * sizeof(double))); part.resize((size_t)nbp); delta.assign((size_t)M + 1, 0.0); }
+    std::vector<double> delta;
+    if (out) delta.assign((size_t)M + 1, 0.0);
     double obj2_pre = 0.0;
     auto finish_out = [&]() {                                 // w = w_pre + delta, delta tiny: first-order update of (obj^2, g)
         double o2 = obj2_pre;
@@ -506,39 +526,16 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     };
     const auto r0 = std::chrono::steady_clock::now();
     for (int it = 0; it < steps; ++it) {
-        PARTLS_HIP_CHECK(hipMemcpyAsync(c->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        PARTLS_HIP_CHECK(launch_residual(c->dX, N, M, c->ldX, out ? c->dy : nullptr, c->wdev.as<double>(), w[(size_t)M],
-                                         out ? c->partial.as<double>() : nullptr, nbp, c->yhatD.as<double>(), c->stream));
-        PARTLS_HIP_CHECK(launch_xtr(c->dX, N, M, c->ldX, c->dy, c->yhatD.as<double>(), c->gD.as<double>(), c->stream));
         bool spd = true;
-        if (it == 0 && !use_tab) spd = factorise();          // overlaps with the kernels just queued (the copy below waits for them)
-        PARTLS_HIP_CHECK(hipMemcpyAsync(gpart.data(), c->gD.p, gpart.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        if (out) PARTLS_HIP_CHECK(hipMemcpyAsync(part.data(), c->partial.p, nbp * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+        // residual (and squared residual) and gradient on the device(s); the Cholesky factorisation, when it is needed, overlaps with them
+        partls_status dst = data_pass(c, w, out != nullptr, true, &obj2_pre, &g, [&]() { if (it == 0 && !use_tab) spd = factorise(); });
+        if (dst != PARTLS_OK) return dst;
         if (out) {
-            obj2_pre = 0.0;
-            for (int b = 0; b < nbp; ++b) obj2_pre += part[(size_t)b];
-            if (c->eta != 0.0)
-                for (int64_t k = 0; k <= c->K; ++k) {
-                    double gs = 0.0;
-                    for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) gs += w[(size_t)m];
-                    obj2_pre += c->eta * gs * gs;
-                }
+            eta_terms(c, w, &obj2_pre, nullptr);
             std::fill(delta.begin(), delta.end(), 0.0);
         }
-        for (int64_t m = 0; m <= M; ++m) {
-            double sg = 0.0;
-            for (int r = 0; r < xr; ++r) sg += gpart[(size_t)r * (M + 1) + m];
-            g[(size_t)m] = sg;
-        }
         if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
-        if (c->eta != 0.0) {                                 // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
-            for (int64_t k = 0; k <= c->K; ++k) {
-                double gs = 0.0;
-                for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) gs += w[(size_t)m];
-                for (int64_t m = 0; m <= M; ++m) if (c->mask_aug[(size_t)m] & (1ULL << k)) g[(size_t)m] -= c->eta * gs;
-            }
-        }
+        eta_terms(c, w, nullptr, &g);                        // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
         if (use_tab) {
             const int nb = (int)tabsup.size();
             const bool elim = !c->faithful;                  // free intercept: rhs and solution go through its Schur complement

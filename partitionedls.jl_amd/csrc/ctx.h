@@ -1,6 +1,7 @@
 // ctx.h — the context behind the opaque partls_ctx handle and the host helpers shared by api.hip and solvers.hip.
 #pragma once
 #include "common.h"
+#include <functional>
 #include <vector>
 
 namespace partls {
@@ -96,6 +97,12 @@ struct partls_ctx {
     // BnB: tableau snapshots of open nodes (solvers.hip: SnapshotPool), kept across fits; host staging of a node batch
     std::vector<void *> bnbChunks;
     size_t bnbSlotBytes = 0;
+    // rows of X sharded over several devices (partls_fit_opt_multi): the contexts that hold the OTHER row blocks of the problem this
+    // context is prepared for; every pass over the data (data_pass, api.hip) then covers them too.  Cleared by every prepare.
+    std::vector<partls_ctx *> peers;
+    std::vector<double> hPart, hGpart;             // host staging of a data pass
+    // called between the Gram build and the tableau preparation (partls_fit_opt_multi: the Gram products of the row blocks are summed)
+    std::function<partls_status(partls_ctx *)> gram_hook;
     std::vector<uint64_t> bnbHostIn;
     std::vector<char> bnbHostOut;
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
@@ -150,6 +157,8 @@ void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes
 // scaled tableau solution -> w over [features, intercept] (length M+1); a free intercept is recovered from the Gram copy
 void unscale_solution(const partls_ctx *c, const double *sol, std::vector<double> &w);
 // ||Xo w - yo||_2 from the data (+ the eta rows): Opt.jl:90
+partls_status data_pass(partls_ctx *c, const std::vector<double> &w, bool want_obj, bool want_grad, double *obj2, std::vector<double> *g,
+                        const std::function<void()> &overlap);
 // grad (optional): Xo'(yo - Xo w) over [features, intercept], from the data (one more pass over X)
 partls_status data_objective(partls_ctx *c, const std::vector<double> &w, double *opt, std::vector<double> *grad = nullptr);
 bool kkt_says_ill_conditioned(const partls_ctx *c);

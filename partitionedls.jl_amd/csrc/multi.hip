@@ -104,6 +104,12 @@ struct partls_multi {
     double win_obj = 0.0;
     int64_t win_pat = -1;
     std::vector<std::vector<double>> t_ms;
+    // row-sharded fits: did rank r get as far as the Gram rendezvous (a rank that failed earlier joins it from its error path), and
+    // the host images of the partial Gram products of the host-reduced (rehearsal) mode
+    std::vector<char> at_gram;
+    std::vector<std::vector<double>> gram_img;
+    bool shard_rows = false;
+    bool replicate = false;                  // PARTLS_MULTI_REPLICATE (read at create): every rank uploads all of X (A/B tests)
 };
 
 namespace {
@@ -172,11 +178,59 @@ partls_status reduce_host(partls_multi *mc, int r, double obj, int64_t pat, doub
     return PARTLS_OK;
 }
 
+// Rows of X sharded over the ranks: every rank has built the Gram products of ITS row block; their sum is the problem's.  Called by
+// ctx_prepare between the Gram build and the tableau preparation (ctx.h: gram_hook), on the rank's thread and stream.  The ranks first
+// agree on the host that ALL of them got here (a rank that failed earlier joins the rendezvous from its error path): nobody may be
+// left waiting inside a collective.  Then  G <- sum_r G_r : ncclAllReduce(ncclSum) over xGMI on (M + 2)^2 doubles padded to ldg^2
+// (0.8 MB at C3) — every rank receives the same bits, so all of them prepare the same tableau and derive the same visiting order —
+// or, in the rehearsal mode without a communicator, the same sum in rank order through host memory.
+partls_status gram_rendezvous(partls_multi *mc, int r, partls_ctx *c)
+{
+    const int R = mc->ndev;
+    mc->at_gram[(size_t)r] = 1;
+    mc->bar.wait();
+    bool all_here = true;
+    for (int q = 0; q < R; ++q) all_here = all_here && mc->at_gram[(size_t)q] == 1;
+    if (!all_here) { set_error("partls_fit_opt_multi: another rank failed before the Gram products could be combined"); return PARTLS_ERR_STATE; }
+    const size_t count = (size_t)c->ldg * c->ldg;
+    if (mc->use_rccl) {
+        Rccl &Rc = rccl();
+        const ncclResult_t e = Rc.AllReduce(c->G.p, c->G.p, count, ncclDouble, ncclSum, mc->comms[(size_t)r], c->stream);
+        if (e != ncclSuccess) { set_error("ncclAllReduce(sum of the Gram products) failed on rank %d: %s", r, Rc.GetErrorString(e)); return PARTLS_ERR_HIP; }
+        return PARTLS_OK;
+    }
+    std::vector<double> &img = mc->gram_img[(size_t)r];
+    img.resize(count);
+    PARTLS_HIP_CHECK(hipMemcpyAsync(img.data(), c->G.p, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    mc->bar.wait();
+    std::vector<double> sum(mc->gram_img[0]);
+    for (int q = 1; q < R; ++q) {
+        const double *src = mc->gram_img[(size_t)q].data();
+        for (size_t i = 0; i < count; ++i) sum[i] += src[i];
+    }
+    mc->bar.wait();                                        // every rank has read the images before anybody's next fit rewrites them
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->G.p, sum.data(), count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));     // `sum` is pageable and goes out of scope
+    return PARTLS_OK;
+}
+
 void rank_main(partls_multi *mc, int r, const FitArgs &a)
 {
     partls_ctx *c = mc->ctx[(size_t)r];
     const int R = mc->ndev;
-    partls_status st = partls_opt_prepare(c, a.X, a.N, a.M, a.ldX, a.y, 0, a.P, a.K, a.ldP, a.eta, a.flags);
+    // rank r uploads and owns rows [r0, r1) of X and y (column-major: a row block is a strided view, uploaded with one 2-D copy): 1 / R of
+    // the PCIe traffic of a replicated upload; every later pass over the data runs on all blocks (ctx.h: peers)
+    const int64_t r0 = mc->shard_rows ? (int64_t)(((__int128)r * a.N) / R) : 0, r1 = mc->shard_rows ? (int64_t)(((__int128)(r + 1) * a.N) / R) : a.N;
+    mc->at_gram[(size_t)r] = 0;
+    c->gram_hook = nullptr;
+    if (mc->shard_rows) c->gram_hook = [mc, r](partls_ctx *cc) { return gram_rendezvous(mc, r, cc); };
+    partls_status st = partls_opt_prepare(c, a.X ? a.X + r0 : nullptr, r1 - r0, a.M, a.ldX, a.y ? a.y + r0 : nullptr, 0, a.P, a.K, a.ldP, a.eta, a.flags);
+    c->gram_hook = nullptr;
+    if (mc->shard_rows && mc->at_gram[(size_t)r] == 0) {  // failed before the rendezvous: join it, so that the others can leave it
+        mc->at_gram[(size_t)r] = 2;
+        mc->bar.wait();
+    }
     double bobj = INFINITY, key = 0.0;
     int64_t bpat = -1, unconv = 0;
     if (st == PARTLS_OK) {
@@ -212,7 +266,10 @@ void rank_main(partls_multi *mc, int r, const FitArgs &a)
     mc->win_obj = gobj;
     mc->win_pat = gpat;
     if (gpat < 0) { set_error("sweep produced no candidate"); fail(mc, 0, PARTLS_ERR_NOT_CONVERGED); return; }
-    st = partls_opt_finish(c, gpat, a.alpha, a.beta, a.t, a.opt, a.best_index);     // the winner is re-solved on the first device
+    // the winner is re-solved on the first device; its passes over the data (refinement, objective, KKT check) cover every rank's
+    // row block: rank 0's thread drives the other devices' streams as well (every rank has finished its sweep: reduce above)
+    if (mc->shard_rows) c->peers.assign(mc->ctx.begin() + 1, mc->ctx.end());
+    st = partls_opt_finish(c, gpat, a.alpha, a.beta, a.t, a.opt, a.best_index);
     mc->t_ms[0][PARTLS_T_FINISH] = c->ms[PARTLS_T_FINISH];
     if (st != PARTLS_OK) fail(mc, 0, st);
 }
@@ -243,6 +300,9 @@ try {
     mc->obj.assign((size_t)ndev, 0.0); mc->key.assign((size_t)ndev, 0.0);
     mc->pat.assign((size_t)ndev, -1); mc->unconv.assign((size_t)ndev, 0);
     mc->all_opt.resize((size_t)ndev);
+    mc->replicate = getenv("PARTLS_MULTI_REPLICATE") != nullptr;
+    mc->at_gram.assign((size_t)ndev, 0);
+    mc->gram_img.resize((size_t)ndev);
     mc->t_ms.assign((size_t)ndev, std::vector<double>((size_t)PARTLS_T_COUNT, 0.0));
     mc->bar.n = ndev;
     mc->red.resize((size_t)ndev);
@@ -315,6 +375,9 @@ try {
     const FitArgs a{X, N, M, ldX, y, P, K, ldP, eta, flags, alpha, beta, t, opt, best_index, all_opt};
     const int R = mc->ndev;
     for (int r = 0; r < R; ++r) { mc->st[(size_t)r] = PARTLS_OK; mc->msg[(size_t)r].clear(); mc->unconv[(size_t)r] = 0; }
+    // rows sharded over the ranks whenever every rank gets a reasonable block (tiny problems: every rank takes all rows — nothing to save)
+    // (one rank: the block is all of X and the sum has one term — the same code path, which is what a one-GPU box can test of it)
+    mc->shard_rows = N >= (int64_t)64 * R && !mc->replicate;
     std::vector<std::thread> th;
     for (int r = 1; r < R; ++r) th.emplace_back(rank_main, mc, r, std::cref(a));
     rank_main(mc, 0, a);                                     // rank 0 on the caller's thread

@@ -133,3 +133,45 @@ def test_raw_ctypes_multi_and_argument_checks(partls):
     assert lib.partls_multi_create(bad, 1, C.byref(h)) == partls.lowlevel.ERR_NO_DEVICE
     assert lib.partls_multi_create(None, -1, C.byref(h)) == partls.lowlevel.ERR_BAD_ARG
     assert lib.partls_multi_size(None) == 0
+
+
+def test_rows_sharded_over_the_ranks(partls, oracle, monkeypatch):
+    """Every rank uploads 1/R of the rows, the Gram products of the blocks are summed (RCCL sum all-reduce; through the host in the
+    one-device rehearsal), and the finish's passes over the data cover every block: same fit as with a replicated upload
+    (PARTLS_MULTI_REPLICATE) and as the oracle — also with eta > 0, with a leading dimension, and when N is not a multiple of R."""
+    X, y, P = _problem(oracle, seed=20260035, N=3001, D=37, K=7)
+    ref = oracle.fit_opt(X, y, P)
+    res = {}
+    for mode in ("shard", "replicate"):
+        if mode == "replicate":
+            monkeypatch.setenv("PARTLS_MULTI_REPLICATE", "1")
+        mc = partls.MultiContext([0, 0, 0])
+        try:
+            res[mode] = mc.fit_opt(X, y, P)
+            # the rank-0 context holds the problem: single patterns are re-solved with data passes over all blocks
+            c0 = mc.context(0); c0._shape = (X.shape[0], X.shape[1], P.shape[1])
+            ra, o5 = c0.opt_finish(5)[0], c0.opt_finish(5)[3]
+            res[mode + "_p5"] = o5
+        finally:
+            mc.close()
+    a, b, t, opt, bi, _ = res["shard"]
+    a2, b2, t2, opt2, bi2, _ = res["replicate"]
+    assert bi == bi2 == ref["best_index"] and abs(opt - opt2) <= 1e-12 * opt2 and abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(a, a2, atol=1e-11)
+    np.testing.assert_allclose(a, ref["alpha"], atol=1e-7)
+    assert abs(res["shard_p5"] - res["replicate_p5"]) <= 1e-12 * res["replicate_p5"]
+    monkeypatch.delenv("PARTLS_MULTI_REPLICATE", raising=False)
+    # eta > 0 (the regularisation rows are added once, not per block) and NaN in ONE rank's block
+    mc = partls.MultiContext([0, 0])
+    try:
+        a, b, t, opt, bi, _ = mc.fit_opt(X, y, P, eta=0.7)
+        refe = oracle.fit_opt(X, y, P, eta=0.7)
+        assert bi == refe["best_index"] and abs(opt - refe["opt"]) <= 1e-9 * max(1.0, refe["opt"])
+        Xn = X.copy(); Xn[2900, 3] = np.inf                                # in the second rank's rows
+        with pytest.raises(partls.PartlsError) as ei:
+            mc.fit_opt(Xn, y, P)
+        assert ei.value.status == partls.lowlevel.ERR_NONFINITE
+        a, b, t, opt, bi, _ = mc.fit_opt(X, y, P)                          # the handle survives
+        assert bi == ref["best_index"]
+    finally:
+        mc.close()
