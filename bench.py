@@ -119,8 +119,8 @@ def main():
         t0 = time.perf_counter()
         if world == 1:          # in-library search: every node warm-started from its parent's tableau snapshot (partls_bnb_search)
             mu, pat, free, bounded = ctx.bnb_search(cap or 0)
-        else:                   # frontier batches dealt over the ranks (cold node bounds: a snapshot lives on one GPU only)
-            mu, pat, free, bounded = pls.dist.bnb_search(ctx.bnb_bound, K + 1, rank=rank, world=world, device=red_dev, max_nodes=cap)
+        else:                   # frontier batches dealt over the ranks, every node to the rank that holds its parent's tableau snapshot
+            mu, pat, free, bounded = pls.dist.bnb_search_warm(ctx, K + 1, rank=rank, world=world, device=red_dev, max_nodes=cap)
         a, b, t, opt = ctx.bnb_leaf(pat, free)
         return dict(opt=opt, nopen=bounded, seconds=time.perf_counter() - t0)
 
@@ -220,7 +220,9 @@ def main():
         if kind == "bnb":
             out["bnb"] = {"seconds": sum(h["bnb"]["seconds"] for h in hist) / len(hist), "nodes_bounded": res["bnb"]["nopen"],
                           "opt": res["bnb"]["opt"], "gap_vs_opt": abs(res["bnb"]["opt"] - res["opt"]) / res["opt"],
-                          "sharding": f"frontier batches of 512 x {world} nodes, one all-gather per batch"}
+                          "sharding": ("in-library search, warm-started node bounds" if world == 1 else
+                                       f"frontier batches of 1024 x {world} nodes, each node bounded by the rank that holds its parent's tableau "
+                                       f"snapshot (warm start), one all-gather per batch")}
     else:
         out["metric"] = "fit(Alt) fits/sec (Gram build + ALS loop); Gram build fp64-MFMA fraction"
         out["unit"] = "fits/s"
@@ -254,6 +256,9 @@ def main():
         mu2, _, _, bounded2 = pls.dist.bnb_search(ctx.bnb_bound, K + 1, max_nodes=args.bnb_cap)
         dt2 = time.perf_counter() - t1
         out["bnb_hard"]["cold_nodes_per_s"] = bounded2 / dt2
+        t1 = time.perf_counter()                             # the host-driven form of the warm search (what N > 1 ranks run): native frontier,
+        mu3, _, _, bounded3 = pls.dist.bnb_search_warm(ctx, K + 1, max_nodes=args.bnb_cap)     # snapshot slots through the C ABI, one rank
+        out["bnb_hard"]["host_driven_warm_nodes_per_s"] = bounded3 / (time.perf_counter() - t1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "alt":
         # the sample of the CPU baseline: the GPU's winner + random patterns (reference indexing, K + 1 bits).  The device's answer for
         # every one of them — from the SWEEP's own per-pattern output (all_opt of a faithful enumeration: what ranks the patterns) and

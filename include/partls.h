@@ -158,6 +158,34 @@ partls_status partls_bnb_bound(partls_ctx *ctx, int64_t count, const uint64_t *p
                                double *lb, int32_t *branch);
 partls_status partls_bnb_leaf(partls_ctx *ctx, uint64_t pat, uint64_t free_groups,
                               double *alpha, double *beta, double *t, double *opt);
+/* Node bounds with tableau SNAPSHOTS, for a host that runs the search itself and shards it over GPUs (dist.py deals every node to the
+ * rank that holds its parent's snapshot): node i starts from the final tableau stored in src_slot[i] (-1: the fresh tableau) and leaves
+ * its own in dst_slot[i] (out; -1: pool full, no free group left, or n > 320).  The host keeps the reference counts and returns slots
+ * with partls_bnb_snap_release; partls_bnb_snap_begin (after every prepare, before the first bound) empties the pool. */
+partls_status partls_bnb_snap_begin(partls_ctx *ctx);
+partls_status partls_bnb_bound_snap(partls_ctx *ctx, int64_t count, const uint64_t *pat, const uint64_t *free_groups,
+                                    const int32_t *src_slot, int32_t *dst_slot, double *lb, int32_t *branch);
+partls_status partls_bnb_snap_release(partls_ctx *ctx, int64_t count, const int32_t *slots);
+/* The FRONTIER of the search as an object, for a host that shards the search over processes (one per GPU): every rank creates one with
+ * its (rank, world) and drives rounds —
+ *   next:    pops the batch * world most promising nodes (pruned against the incumbent, BnB.jl:102) and deals them: a node goes to the
+ *            rank that holds its parent's snapshot, up to that rank's quota; the rest, cold, to the least loaded ranks.  *total = nodes
+ *            of the round (0: the search is over), per_rank[world] = every rank's share, this rank's share in pat / free_groups /
+ *            src_slot (capacity >= batch) ready for partls_bnb_bound_snap;
+ *   (the ranks exchange lb / branch / dst_slot of their shares: one all-gather)
+ *   ingest:  the results of ALL ranks in rank-major order (rank 0's nodes in the order `next` gave them, then rank 1's, ...): prunes,
+ *            records feasible nodes, branches (BnB.jl:107-124), counts snapshot references; `dead` receives this rank's slots that lost
+ *            their last reference (at most dead_capacity per call; call again with an empty round for the rest) for
+ *            partls_bnb_snap_release.
+ * All ranks make identical decisions (the frontier depends on shared data only).  partls_bnb_search is this loop with world = 1. */
+typedef struct partls_frontier partls_frontier;
+partls_status partls_frontier_create(int n_groups, int rank, int world, int64_t batch, partls_frontier **out);
+void          partls_frontier_destroy(partls_frontier *f);
+partls_status partls_frontier_next(partls_frontier *f, int64_t *total, int64_t *mine, uint64_t *pat, uint64_t *free_groups,
+                                   int32_t *src_slot, int32_t *per_rank);
+partls_status partls_frontier_ingest(partls_frontier *f, const double *lb, const int32_t *branch, const int32_t *dst_slot,
+                                     int32_t *dead, int64_t dead_capacity, int64_t *ndead);
+partls_status partls_frontier_result(const partls_frontier *f, double *mu, uint64_t *pat, uint64_t *free_groups, int64_t *nodes);
 /* The search itself (what partls_fit_bnb / partls_bnb_prepared run before partls_bnb_leaf): best-first frontier, device batches,
  * every node warm-started from its parent's final tableau, which stays in HBM while the node has children in the frontier
  * (BnB.jl:120-124: a child is the parent's constraint set plus one group).  Returns the incumbent node (pat, free_groups), its

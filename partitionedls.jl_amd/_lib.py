@@ -47,6 +47,16 @@ SYMBOLS = [
     ("partls_alt_prepared", C.c_int, [C.c_void_p, C.c_double, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     ("partls_bnb_prepared", C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _ip]),
     ("partls_bnb_bound", C.c_int, [C.c_void_p, _i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _dp, C.POINTER(C.c_int32)]),
+    ("partls_bnb_snap_begin", C.c_int, [C.c_void_p]),
+    ("partls_bnb_bound_snap", C.c_int, [C.c_void_p, _i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), _dp, C.POINTER(C.c_int32)]),
+    ("partls_bnb_snap_release", C.c_int, [C.c_void_p, _i64, C.POINTER(C.c_int32)]),
+    ("partls_frontier_create", C.c_int, [C.c_int, C.c_int, C.c_int, _i64, C.POINTER(C.c_void_p)]),
+    ("partls_frontier_destroy", None, [C.c_void_p]),
+    ("partls_frontier_next", C.c_int, [C.c_void_p, _ip, _ip, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32)]),
+    ("partls_frontier_ingest", C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i64, _ip]),
+    ("partls_frontier_result", C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
     ("partls_bnb_search", C.c_int, [C.c_void_p, _i64, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
     ("partls_bnb_leaf", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, _dp, _dp, _dp, _dp]),
     ("partls_predict", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, _i64, _i64, _dp, _dp, C.c_double, _dp]),

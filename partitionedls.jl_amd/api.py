@@ -186,6 +186,28 @@ class Context:
                                             br.ctypes.data_as(C.POINTER(C.c_int32))))
         return lb, br
 
+    def bnb_snap_begin(self):
+        _check(L.lib().partls_bnb_snap_begin(self._h))
+
+    def bnb_bound_snap(self, pats, frees, src_slots):
+        """bnb_bound with tableau snapshots: node i starts from slot src_slots[i] (-1: fresh tableau); returns (lb, branch, dst_slots)."""
+        pats = np.ascontiguousarray(pats, dtype=np.uint64)
+        frees = np.ascontiguousarray(frees, dtype=np.uint64)
+        src = np.ascontiguousarray(src_slots, dtype=np.int32)
+        n = len(pats)
+        lb = np.zeros(n); br = np.zeros(n, dtype=np.int32); dst = np.full(n, -1, dtype=np.int32)
+        if n:
+            i32 = C.POINTER(C.c_int32)
+            _check(L.lib().partls_bnb_bound_snap(self._h, n, pats.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                 frees.ctypes.data_as(C.POINTER(C.c_uint64)), src.ctypes.data_as(i32),
+                                                 dst.ctypes.data_as(i32), _dp(lb), br.ctypes.data_as(i32)))
+        return lb, br, dst
+
+    def bnb_snap_release(self, slots):
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        if len(sl):
+            _check(L.lib().partls_bnb_snap_release(self._h, len(sl), sl.ctypes.data_as(C.POINTER(C.c_int32))))
+
     def bnb_search(self, max_nodes=0):
         """The BnB search on a prepared faithful context (warm-started node bounds): (mu, pat, free, nodes_bounded)."""
         mu = C.c_double(); pat = C.c_uint64(); fr = C.c_uint64(); nn = C.c_int64()
@@ -235,6 +257,54 @@ class Context:
     def synth_device(self, seed, N, D, wstar, dX_ptr, dy_ptr):
         ws = np.ascontiguousarray(wstar, dtype=np.float64)
         _check(L.lib().partls_synth_device(self._h, C.c_uint64(seed), N, D, _dp(ws), C.c_void_p(dX_ptr), C.c_void_p(dy_ptr)))
+
+
+class Frontier:
+    """The frontier of the BnB search as a native object (include/partls.h: partls_frontier_*): pops and deals rounds of nodes,
+    ingests the ranks' (bound, branch, snapshot slot) triples, keeps the snapshot reference counts.  dist.bnb_search_warm drives it."""
+
+    def __init__(self, n_groups, rank=0, world=1, batch=1024):
+        self._h = C.c_void_p()
+        _check(L.lib().partls_frontier_create(int(n_groups), int(rank), int(world), int(batch), C.byref(self._h)))
+        self.world, self.batch = int(world), int(batch)
+        self._pat = np.zeros(self.batch, dtype=np.uint64); self._free = np.zeros(self.batch, dtype=np.uint64)
+        self._src = np.zeros(self.batch, dtype=np.int32); self._per = np.zeros(self.world, dtype=np.int32)
+        self._dead = np.zeros(4 * self.batch * self.world + 64, dtype=np.int32)
+
+    def close(self):
+        if self._h:
+            L.lib().partls_frontier_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def next(self):
+        """(total, pats, frees, src_slots, per_rank): this rank's share of the next round (views valid until the next call)"""
+        tot = C.c_int64(); mine = C.c_int64()
+        u64 = C.POINTER(C.c_uint64); i32 = C.POINTER(C.c_int32)
+        _check(L.lib().partls_frontier_next(self._h, C.byref(tot), C.byref(mine), self._pat.ctypes.data_as(u64), self._free.ctypes.data_as(u64),
+                                            self._src.ctypes.data_as(i32), self._per.ctypes.data_as(i32)))
+        m = mine.value
+        return tot.value, self._pat[:m], self._free[:m], self._src[:m], self._per.copy()
+
+    def ingest(self, lb, branch, dst):
+        """results of the whole round in rank-major order; returns this rank's dead snapshot slots"""
+        lb = np.ascontiguousarray(lb, dtype=np.float64); br = np.ascontiguousarray(branch, dtype=np.int32)
+        ds = np.ascontiguousarray(dst, dtype=np.int32)
+        nd = C.c_int64()
+        i32 = C.POINTER(C.c_int32)
+        _check(L.lib().partls_frontier_ingest(self._h, _dp(lb), br.ctypes.data_as(i32), ds.ctypes.data_as(i32),
+                                              self._dead.ctypes.data_as(i32), len(self._dead), C.byref(nd)))
+        return self._dead[:nd.value].copy()
+
+    def result(self):
+        mu = C.c_double(); pat = C.c_uint64(); fr = C.c_uint64(); nn = C.c_int64()
+        _check(L.lib().partls_frontier_result(self._h, C.byref(mu), C.byref(pat), C.byref(fr), C.byref(nn)))
+        return mu.value, pat.value, fr.value, nn.value
 
 
 class MultiContext:

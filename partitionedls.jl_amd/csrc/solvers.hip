@@ -55,16 +55,15 @@ bool solve_dense(std::vector<double> &H, std::vector<double> &g, int n)
 // ~n/2 variables from scratch.  Slots live in chunks that are allocated on demand and kept by the context (288 GB of HBM:
 // the default cap of 16 GB holds ~50 000 open nodes at n = 257); when the pool is full a node simply leaves no snapshot and
 // its children start from the fresh tableau.
-struct SnapshotPool {
+struct SnapshotPool {                                              // a view of the pool state the context keeps (ctx.h: bnb*)
     partls_ctx *c;
-    size_t slot_bytes = 0;
     static constexpr int CHUNK = 512;
-    std::vector<int> free_list, refs;
-    size_t max_slots = 0;
+    std::vector<int> &free_list, &refs;
+    explicit SnapshotPool(partls_ctx *ctx) : c(ctx), free_list(ctx->bnbFree), refs(ctx->bnbRefs) {}
 
     hipError_t begin(size_t bytes)
     {
-        slot_bytes = (bytes + 255) & ~(size_t)255;
+        const size_t slot_bytes = (bytes + 255) & ~(size_t)255;
         if (c->bnbSlotBytes != slot_bytes) {                       // another tableau size: the old chunks are useless
             for (void *q : c->bnbChunks) (void)hipFree(q);
             c->bnbChunks.clear();
@@ -74,19 +73,20 @@ struct SnapshotPool {
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         size_t cap = (size_t)c->knobs.bnb_pool_mb << 20;
         cap = std::min(cap, free_b / 2 + c->bnbChunks.size() * CHUNK * slot_bytes);
-        max_slots = cap / slot_bytes;
+        c->bnbMaxSlots = cap / slot_bytes;
         free_list.clear();
         refs.assign(c->bnbChunks.size() * CHUNK, 0);
         for (int i = (int)refs.size() - 1; i >= 0; --i) free_list.push_back(i);
         return hipSuccess;
     }
-    double *ptr(int slot) const { return reinterpret_cast<double *>(static_cast<char *>(c->bnbChunks[(size_t)slot / CHUNK]) + (size_t)(slot % CHUNK) * slot_bytes); }
+    bool valid(int slot) const { return slot >= 0 && (size_t)slot < c->bnbChunks.size() * CHUNK; }
+    double *ptr(int slot) const { return reinterpret_cast<double *>(static_cast<char *>(c->bnbChunks[(size_t)slot / CHUNK]) + (size_t)(slot % CHUNK) * c->bnbSlotBytes); }
     int alloc()                                                    // -1: pool exhausted
     {
         if (free_list.empty()) {
-            if ((c->bnbChunks.size() + 1) * CHUNK > max_slots) return -1;
+            if ((c->bnbChunks.size() + 1) * CHUNK > c->bnbMaxSlots) return -1;
             void *q = nullptr;
-            if (hipMalloc(&q, (size_t)CHUNK * slot_bytes) != hipSuccess) { (void)hipGetLastError(); max_slots = 0; return -1; }
+            if (hipMalloc(&q, (size_t)CHUNK * c->bnbSlotBytes) != hipSuccess) { (void)hipGetLastError(); c->bnbMaxSlots = 0; return -1; }
             const int base = (int)c->bnbChunks.size() * CHUNK;
             c->bnbChunks.push_back(q);
             refs.resize((size_t)base + CHUNK, 0);
@@ -100,6 +100,8 @@ struct SnapshotPool {
     void release(int slot) { if (slot >= 0 && --refs[(size_t)slot] <= 0) free_list.push_back(slot); }
     void drop(int slot) { if (slot >= 0) free_list.push_back(slot); }          // a slot nobody references
 };
+
+size_t snapshot_bytes(const partls_ctx *c) { return sweep_reg_t0_doubles(c->T) * sizeof(double) + (size_t)16 * c->T; }
 
 // Bound `cnt` nodes (pat, free) on the register kernel: codes, node solves (warm-started from src[i] when given, final state
 // stored to dst[i] when given) and (bound, branch) all on the device; one upload, one download, one synchronisation per batch.
@@ -169,6 +171,106 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
 }
 
 }  // namespace
+
+// ---- the frontier of the BnB search (host runtime, shared by the in-library search and the rank-sharded one of dist.py) ----------------
+// fit_BnB (BnB.jl:94-132) as a best-first search: the frontier is ordered by the parent's bound, a round pops the `batch * world` most
+// promising nodes (pruned against the incumbent, BnB.jl:102), DEALS them to the ranks, and — once every rank has bounded its share and
+// the (bound, branch, snapshot slot) triples have been exchanged — branches the survivors (BnB.jl:117-124).  Every rank runs the same
+// frontier on the same data, so it never has to be exchanged; only the triples are.  Dealing: a node whose parent left a tableau
+// snapshot goes to the rank that holds it (warm start) up to that rank's quota of the round; what exceeds the quota and every node
+// without a snapshot goes to the least loaded ranks and starts cold there (the tree spreads over the ranks by itself).  The frontier
+// also keeps the reference counts of the snapshots (two children per branched node) and tells each rank which of ITS slots died.
+struct partls_frontier {
+    struct Node { double key; uint64_t pat, free_; unsigned long long seq; int owner, slot; };
+    struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
+    std::priority_queue<Node, std::vector<Node>, Cmp> heap;
+    int rank = 0, world = 1;
+    int64_t batch = 1024, bounded = 0;
+    unsigned long long seq = 0;
+    double mu = INFINITY;
+    uint64_t best_pat = 0, best_free = 0;
+    std::vector<std::vector<int>> refs;              // [owner][slot]: children of that snapshot still in the frontier or in flight
+    std::vector<Node> round;                         // the nodes of the current round, in popping order
+    std::vector<int> assign;                         // rank of every node of the round
+    std::vector<char> warm;                          // it starts from its parent's snapshot there
+    std::vector<int> dead;                           // this rank's slots that lost their last reference
+
+    void unref(int owner, int slot)
+    {
+        if (owner < 0) return;
+        if (--refs[(size_t)owner][(size_t)slot] == 0 && owner == rank) dead.push_back(slot);
+    }
+    void setref(int owner, int slot, int v)
+    {
+        std::vector<int> &r = refs[(size_t)owner];
+        if ((size_t)slot >= r.size()) r.resize((size_t)slot + 1024, 0);
+        r[(size_t)slot] = v;
+    }
+    // pops and deals the next round; per_rank[world] = nodes of every rank; this rank's share into pat / free / src (capacity: batch)
+    int64_t next(int64_t *mine, uint64_t *pat, uint64_t *fre, int32_t *src, int32_t *per_rank)
+    {
+        round.clear();
+        while (!heap.empty() && (int64_t)round.size() < batch * world) {
+            const Node nd = heap.top();
+            heap.pop();
+            if (nd.key >= mu) { unref(nd.owner, nd.slot); continue; }        // its bound can only be >= the parent's
+            round.push_back(nd);
+        }
+        const int64_t cnt = (int64_t)round.size();
+        const int64_t quota = (cnt + world - 1) / world;
+        std::vector<int64_t> load((size_t)world, 0);
+        assign.assign((size_t)cnt, -1);
+        warm.assign((size_t)cnt, 0);
+        for (int64_t i = 0; i < cnt; ++i) {
+            const int o = round[(size_t)i].owner;
+            if (o >= 0 && load[(size_t)o] < quota) { assign[(size_t)i] = o; warm[(size_t)i] = 1; ++load[(size_t)o]; }
+        }
+        for (int64_t i = 0; i < cnt; ++i) {
+            if (assign[(size_t)i] >= 0) continue;
+            int r = 0;
+            for (int q = 1; q < world; ++q) if (load[(size_t)q] < load[(size_t)r]) r = q;
+            assign[(size_t)i] = r; ++load[(size_t)r];
+        }
+        int64_t m = 0;
+        for (int64_t i = 0; i < cnt; ++i)
+            if (assign[(size_t)i] == rank) {
+                pat[m] = round[(size_t)i].pat; fre[m] = round[(size_t)i].free_;
+                src[m] = warm[(size_t)i] ? round[(size_t)i].slot : -1;
+                ++m;
+            }
+        for (int q = 0; q < world; ++q) per_rank[q] = (int32_t)load[(size_t)q];
+        *mine = m;
+        return cnt;
+    }
+    // results of the round in RANK-MAJOR order (rank 0's nodes in the order next() gave them to rank 0, then rank 1's, ...)
+    void ingest(const double *lb, const int32_t *br, const int32_t *dst)
+    {
+        const int64_t cnt = (int64_t)round.size();
+        std::vector<int64_t> at((size_t)world, 0), base((size_t)world + 1, 0);
+        for (int64_t i = 0; i < cnt; ++i) ++base[(size_t)assign[(size_t)i] + 1];
+        for (int q = 0; q < world; ++q) base[(size_t)q + 1] += base[(size_t)q];
+        for (int64_t i = 0; i < cnt; ++i) {
+            const Node &nd = round[(size_t)i];
+            const int me = assign[(size_t)i];
+            const int64_t j = base[(size_t)me] + at[(size_t)me]++;
+            ++bounded;
+            unref(nd.owner, nd.slot);                                         // this child no longer needs its parent's tableau
+            const double l = lb[j];
+            const int k = br[j], d = dst[j];
+            if (l >= mu || k < 0) {
+                if (l < mu) { mu = l; best_pat = nd.pat; best_free = nd.free_; }   // feasible for the original problem (BnB.jl:109-115)
+                if (d >= 0 && me == rank) dead.push_back(d);
+                continue;
+            }
+            const uint64_t bit = 1ULL << k;
+            if (d >= 0) setref(me, d, 2);                                     // both children start from this node's tableau
+            const int o = d >= 0 ? me : -1, sl = d >= 0 ? d : -1;
+            heap.push({l, nd.pat | bit, nd.free_ & ~bit, seq++, o, sl});      // alpha_pk >= 0 first (BnB.jl:120,123)
+            heap.push({l, nd.pat & ~bit, nd.free_ & ~bit, seq++, o, sl});     // alpha_pk <= 0
+        }
+        round.clear();
+    }
+};
 
 extern "C" {
 
@@ -361,6 +463,66 @@ try {
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
 catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
+// The same with tableau snapshots, for a host that runs the search itself (partitionedls.jl_amd/dist.py: the rank-sharded search deals
+// every node to the rank that holds its parent's snapshot).  src_slot[i]: snapshot node i starts from (-1: the fresh tableau);
+// dst_slot[i] (out): the slot that now holds node i's final tableau, -1 when the pool is full, the node has no free group left, or the
+// tableau is not register-resident (n > 320: cold bounds only).  The host owns the reference counts and returns slots with
+// partls_bnb_snap_release; partls_bnb_snap_begin empties the pool for a new search.
+partls_status partls_bnb_snap_begin(partls_ctx *c)
+try {
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_snap_begin: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    if (!c->use_reg) { c->bnbFree.clear(); c->bnbRefs.clear(); c->bnbMaxSlots = 0; return PARTLS_OK; }
+    SnapshotPool pool(c);
+    PARTLS_HIP_CHECK(pool.begin(snapshot_bytes(c)));
+    return PARTLS_OK;
+}
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_bnb_bound_snap(partls_ctx *c, int64_t count, const uint64_t *pat, const uint64_t *free_, const int32_t *src_slot,
+                                    int32_t *dst_slot, double *lb, int32_t *branch)
+try {
+    if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound_snap: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
+    if (count < 0 || (count > 0 && (!pat || !free_ || !src_slot || !dst_slot || !lb || !branch))) { set_error("partls_bnb_bound_snap: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    if (!c->use_reg || c->knobs.bnb_cold) {                    // no snapshots on the global-memory kernels
+        for (int64_t i = 0; i < count; ++i) dst_slot[i] = -1;
+        return partls_bnb_bound(c, count, pat, free_, lb, branch);
+    }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    SnapshotPool pool(c);
+    if (c->bnbSlotBytes != ((snapshot_bytes(c) + 255) & ~(size_t)255)) { set_error("partls_bnb_bound_snap: call partls_bnb_snap_begin after preparing the problem"); return PARTLS_ERR_STATE; }
+    std::vector<const double *> srcp((size_t)count);
+    std::vector<double *> dstp((size_t)count);
+    for (int64_t i = 0; i < count; ++i) {
+        if (src_slot[i] >= 0 && !pool.valid(src_slot[i])) { set_error("partls_bnb_bound_snap: src_slot[%lld] = %d is no slot of this context", (long long)i, src_slot[i]); return PARTLS_ERR_BAD_ARG; }
+        dst_slot[i] = free_[i] ? pool.alloc() : -1;
+        srcp[(size_t)i] = src_slot[i] >= 0 ? pool.ptr(src_slot[i]) : nullptr;
+        dstp[(size_t)i] = dst_slot[i] >= 0 ? pool.ptr(dst_slot[i]) : nullptr;
+    }
+    unsigned long long unc = 0;
+    partls_status st = bnb_bound_batch(c, (size_t)count, pat, free_, srcp.data(), dstp.data(), lb, branch, &unc);
+    if (st != PARTLS_OK) return st;
+    if (unc) { set_error("partls_bnb_bound_snap: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    return PARTLS_OK;
+}
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_bnb_snap_release(partls_ctx *c, int64_t count, const int32_t *slots)
+try {
+    if (!c || count < 0 || (count > 0 && !slots)) { set_error("partls_bnb_snap_release: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    SnapshotPool pool(c);
+    for (int64_t i = 0; i < count; ++i)
+        if (slots[i] >= 0) {
+            if (!pool.valid(slots[i])) { set_error("partls_bnb_snap_release: %d is no slot of this context", slots[i]); return PARTLS_ERR_BAD_ARG; }
+            pool.drop(slots[i]);
+        }
+    return PARTLS_OK;
+}
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
 // The model of one (feasible) node: re-solve, data-space refinement, BnB.jl:36-39 normalisation, objective from the data.
 partls_status partls_bnb_leaf(partls_ctx *c, uint64_t pat, uint64_t free_, double *alpha, double *beta, double *t, double *opt)
 try {
@@ -422,75 +584,88 @@ try {
     if (!mu_out || !pat_out || !free_out) { set_error("partls_bnb_search: NULL output"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     const int Kp = (int)c->K + 1;
-    struct Node { double key; uint64_t pat, free_; unsigned long long seq; int slot; };     // slot: the PARENT's snapshot (-1: none)
-    struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
-    std::priority_queue<Node, std::vector<Node>, Cmp> frontier;
-    unsigned long long seq = 0;
-    frontier.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, seq++, -1});        // root: everything free (Σ = [], BnB.jl:33)
-    double mu = INFINITY;
-    uint64_t best_pat = 0, best_free = ((uint64_t)1 << Kp) - 1;
-    int64_t bounded = 0;
-    const bool warm = c->use_reg && !c->knobs.bnb_cold;
-    const size_t BATCH = (size_t)std::max(1, c->knobs.bnb_batch);
-    SnapshotPool pool{c};
-    if (warm) PARTLS_HIP_CHECK(pool.begin((sweep_reg_t0_doubles(c->T)) * sizeof(double) + (size_t)16 * c->T));
-    std::vector<uint64_t> bp, bf;
-    std::vector<int> pslot, dslot;
-    std::vector<const double *> srcp;
-    std::vector<double *> dstp;
-    std::vector<double> lb;
-    std::vector<int32_t> br;
-    unsigned long long unconv_total = 0;
-    while (!frontier.empty() && !(max_nodes > 0 && bounded >= max_nodes)) {
-        bp.clear(); bf.clear(); pslot.clear();
-        while (!frontier.empty() && bp.size() < BATCH) {
-            const Node nd = frontier.top();
-            frontier.pop();
-            if (nd.key >= mu) { if (warm) pool.release(nd.slot); continue; }   // its bound can only be >= the parent's
-            bp.push_back(nd.pat); bf.push_back(nd.free_); pslot.push_back(nd.slot);
+    partls_frontier f;
+    f.batch = std::max(1, c->knobs.bnb_batch);
+    f.refs.resize(1);
+    f.best_free = ((uint64_t)1 << Kp) - 1;
+    f.heap.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, f.seq++, -1, -1});     // root: everything free (Σ = [], BnB.jl:33)
+    partls_status st = partls_bnb_snap_begin(c);
+    if (st != PARTLS_OK) return st;
+    const size_t cap = (size_t)f.batch;
+    std::vector<uint64_t> bp(cap), bf(cap);
+    std::vector<int32_t> src(cap), dst(cap), br(cap);
+    std::vector<double> lb(cap);
+    int32_t per_rank = 0;
+    while (!(max_nodes > 0 && f.bounded >= max_nodes)) {
+        int64_t mine = 0;
+        const int64_t cnt = f.next(&mine, bp.data(), bf.data(), src.data(), &per_rank);
+        if (cnt > 0) {
+            st = partls_bnb_bound_snap(c, cnt, bp.data(), bf.data(), src.data(), dst.data(), lb.data(), br.data());
+            if (st != PARTLS_OK) return st;
+            f.ingest(lb.data(), br.data(), dst.data());
         }
-        if (bp.empty()) break;
-        const size_t cnt = bp.size();
-        lb.resize(cnt); br.resize(cnt);
-        partls_status st;
-        if (c->use_reg) {
-            unsigned long long unc = 0;
-            if (warm) {
-                dslot.resize(cnt); srcp.resize(cnt); dstp.resize(cnt);
-                for (size_t i = 0; i < cnt; ++i) {
-                    // a node whose groups are all branched cannot branch again: no snapshot needed
-                    dslot[i] = __builtin_popcountll(bf[i]) > 0 ? pool.alloc() : -1;
-                    srcp[i] = pslot[i] >= 0 ? pool.ptr(pslot[i]) : nullptr;
-                    dstp[i] = dslot[i] >= 0 ? pool.ptr(dslot[i]) : nullptr;
-                }
-                st = bnb_bound_batch(c, cnt, bp.data(), bf.data(), srcp.data(), dstp.data(), lb.data(), br.data(), &unc);
-            } else {
-                st = bnb_bound_batch(c, cnt, bp.data(), bf.data(), nullptr, nullptr, lb.data(), br.data(), &unc);
-            }
-            unconv_total += unc;
-        } else {
-            st = partls_bnb_bound(c, (int64_t)cnt, bp.data(), bf.data(), lb.data(), br.data());
+        if (!f.dead.empty()) {
+            st = partls_bnb_snap_release(c, (int64_t)f.dead.size(), f.dead.data());
+            if (st != PARTLS_OK) return st;
+            f.dead.clear();
         }
-        if (st != PARTLS_OK) return st;
-        for (size_t i = 0; i < cnt; ++i) {
-            ++bounded;
-            const int mine = warm ? dslot[i] : -1;
-            if (warm) pool.release(pslot[i]);                              // this child no longer needs its parent's tableau
-            if (lb[i] >= mu) { if (warm) pool.drop(mine); continue; }      // BnB.jl:102
-            if (br[i] < 0) { mu = lb[i]; best_pat = bp[i]; best_free = bf[i]; if (warm) pool.drop(mine); continue; }   // BnB.jl:109-115
-            const uint64_t bit = 1ULL << br[i];
-            if (mine >= 0) pool.refs[(size_t)mine] = 2;                    // both children start from this node's tableau
-            frontier.push({lb[i], bp[i] | bit, bf[i] & ~bit, seq++, mine});     // α_pk >= 0 first (BnB.jl:120,123)
-            frontier.push({lb[i], bp[i] & ~bit, bf[i] & ~bit, seq++, mine});    // α_pk <= 0
-        }
+        if (cnt == 0) break;
     }
-    *mu_out = mu; *pat_out = best_pat; *free_out = best_free;
-    if (nodes_out) *nodes_out = bounded;
-    if (unconv_total) { set_error("partls_bnb_search: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    *mu_out = f.mu; *pat_out = f.best_pat; *free_out = f.best_free;
+    if (nodes_out) *nodes_out = f.bounded;
     return PARTLS_OK;
 }
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
 catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+// ---- the frontier behind the C ABI: what a host that shards the search over processes drives (partitionedls.jl_amd/dist.py) ------------
+partls_status partls_frontier_create(int n_groups, int rank, int world, int64_t batch, partls_frontier **out)
+try {
+    if (!out) { set_error("partls_frontier_create: out is NULL"); return PARTLS_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (n_groups < 1 || n_groups > 62 || world < 1 || rank < 0 || rank >= world || batch < 1) { set_error("partls_frontier_create: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    partls_frontier *f = new partls_frontier();
+    f->rank = rank; f->world = world; f->batch = batch;
+    f->refs.resize((size_t)world);
+    f->best_free = ((uint64_t)1 << n_groups) - 1;
+    f->heap.push({0.0, 0ULL, ((uint64_t)1 << n_groups) - 1, f->seq++, -1, -1});
+    *out = f;
+    return PARTLS_OK;
+}
+catch (...) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+
+void partls_frontier_destroy(partls_frontier *f) { delete f; }
+
+partls_status partls_frontier_next(partls_frontier *f, int64_t *total, int64_t *mine, uint64_t *pat, uint64_t *free_groups, int32_t *src_slot,
+                                   int32_t *per_rank)
+try {
+    if (!f || !total || !mine || !pat || !free_groups || !src_slot || !per_rank) { set_error("partls_frontier_next: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    if (!f->round.empty()) { set_error("partls_frontier_next: the previous round has not been ingested"); return PARTLS_ERR_STATE; }
+    *total = f->next(mine, pat, free_groups, src_slot, per_rank);
+    return PARTLS_OK;
+}
+catch (...) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_frontier_ingest(partls_frontier *f, const double *lb, const int32_t *branch, const int32_t *dst_slot, int32_t *dead,
+                                     int64_t dead_capacity, int64_t *ndead)
+try {
+    if (!f || !ndead || (!f->round.empty() && (!lb || !branch || !dst_slot))) { set_error("partls_frontier_ingest: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    f->ingest(lb, branch, dst_slot);
+    const int64_t nd = (int64_t)f->dead.size() < dead_capacity ? (int64_t)f->dead.size() : dead_capacity;
+    for (int64_t i = 0; i < nd; ++i) dead[i] = f->dead[f->dead.size() - 1 - (size_t)i];
+    f->dead.resize(f->dead.size() - (size_t)nd);               // what did not fit comes with the next call
+    *ndead = nd;
+    return PARTLS_OK;
+}
+catch (...) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_frontier_result(const partls_frontier *f, double *mu, uint64_t *pat, uint64_t *free_groups, int64_t *nodes)
+{
+    if (!f || !mu || !pat || !free_groups) { set_error("partls_frontier_result: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *mu = f->mu; *pat = f->best_pat; *free_groups = f->best_free;
+    if (nodes) *nodes = f->bounded;
+    return PARTLS_OK;
+}
 
 partls_status partls_bnb_prepared(partls_ctx *c, double *alpha, double *beta, double *t, double *opt, int64_t *nopen)
 try {

@@ -106,3 +106,58 @@ def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, devic
             return mu, 0, (1 << n_groups) - 1, bounded
         raise RuntimeError("bnb_search: no feasible leaf found")
     return mu, best[0], best[1], bounded
+
+
+def bnb_search_warm(ctx, n_groups, rank=0, world=1, group=None, batch=1024, device=None, max_nodes=None):
+    """The rank-sharded best-first search of bnb_search with WARM-STARTED node bounds and a NATIVE frontier: a node is bounded on the
+    rank that holds its parent's tableau snapshot (Context.bnb_bound_snap), so a child exchanges only the variables of the one group
+    that was branched instead of being solved from the fresh tableau (4-5x fewer device cycles per node), and all
+    per-node bookkeeping — popping, pruning, dealing, branching, snapshot reference counts — runs in the library
+    (include/partls.h: partls_frontier_*), a few calls per ROUND of `batch * world` nodes; Python only carries the one all-gather of
+    (bound, branch, new slot) per round.
+
+    Every rank runs the same frontier on the same data.  Dealing: a node with a snapshot goes to its owner, up to the owner's quota
+    of the round; what exceeds it, and every node without a snapshot, goes to the least loaded ranks and starts COLD there (the work
+    spreads over the ranks by itself: the root's children are owned by rank 0, their surplus seeds subtrees elsewhere).
+    Returns (mu, best_pat, best_free, nodes_bounded) like bnb_search."""
+    import numpy as np
+    from .api import Frontier
+    use_dist = world > 1
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+    ctx.bnb_snap_begin()
+    fr = Frontier(n_groups, rank, world, batch)
+    try:
+        while True:
+            if max_nodes is not None and fr.result()[3] >= max_nodes:
+                break
+            total, pats, frees, srcs, per_rank = fr.next()
+            if total == 0:
+                ctx.bnb_snap_release(fr.ingest(np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)))
+                break
+            lb_l, br_l, dst_l = ctx.bnb_bound_snap(pats, frees, srcs)
+            if use_dist:
+                per = int(per_rank.max())                        # equal-sized slots so that one all_gather fits every rank
+                mine = len(pats)
+                buf = torch.full((3 * per,), float("nan"), dtype=torch.float64, device=device)
+                buf[:mine] = torch.as_tensor(np.asarray(lb_l, dtype=np.float64))
+                buf[per:per + mine] = torch.as_tensor(np.asarray(br_l, dtype=np.float64))
+                buf[2 * per:2 * per + mine] = torch.as_tensor(np.asarray(dst_l, dtype=np.float64))
+                out = [torch.empty_like(buf) for _ in range(world)]
+                dist.all_gather(out, buf, group=group)
+                o = [t.cpu().numpy() for t in out]
+                lb = np.concatenate([o[r][:per_rank[r]] for r in range(world)])
+                br = np.concatenate([o[r][per:per + per_rank[r]] for r in range(world)]).astype(np.int32)
+                dst = np.concatenate([o[r][2 * per:2 * per + per_rank[r]] for r in range(world)]).astype(np.int32)
+            else:
+                lb, br, dst = lb_l, br_l, dst_l
+            ctx.bnb_snap_release(fr.ingest(lb, br, dst))
+        mu, pat, free, bounded = fr.result()
+    finally:
+        fr.close()
+    if not (mu < float("inf")):
+        if max_nodes is not None:
+            return mu, 0, (1 << n_groups) - 1, bounded
+        raise RuntimeError("bnb_search_warm: no feasible leaf found")
+    return mu, pat, free, bounded

@@ -82,4 +82,6 @@ def test_multi_device_entry_without_gpu(partls):
     h = C.c_void_p()
     assert lib.partls_multi_create(None, 0, C.byref(h)) == partls.lowlevel.ERR_NO_DEVICE and not h
     assert lib.partls_multi_size(None) == 0 and lib.partls_multi_uses_rccl(None) == 0
-    assert "librccl" not in open("/proc/self/maps").read()
+    import sys
+    if "torch" not in sys.modules:                               # PyTorch brings its own copy of RCCL into the process
+        assert "librccl" not in open("/proc/self/maps").read()

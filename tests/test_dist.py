@@ -171,3 +171,78 @@ def test_bnb_search_sharded_gloo_world2(partls, oracle):
         mu, pat, free, bounded = out[r]
         assert (pat, free) == (single[1], single[2]) and abs(mu - single[0]) <= 1e-12 * max(1.0, single[0])
     assert out[0][3] == out[1][3]                                # replicated frontier: identical node counts on both ranks
+
+
+class _FakeSnapCtx:
+    """Stands in for Context in bnb_search_warm on the CPU: bounds come from the oracle; the snapshot pool is bookkeeping only, which
+    is what the test checks — every slot handed out is returned exactly once, nobody starts from a slot that is not live."""
+
+    def __init__(self, X, y, P, capacity=10_000):
+        self._bound = _oracle_bound_fn(X, y, P)
+        self.capacity = capacity
+        self.live = set()
+        self.next = 0
+        self.handed = 0
+        self.warm = 0
+        self.cold = 0
+
+    def bnb_snap_begin(self):
+        self.live.clear()
+
+    def bnb_bound_snap(self, pats, frees, srcs):
+        import numpy as np
+        lb, br = self._bound(pats, frees)
+        dst = np.full(len(pats), -1, dtype=np.int32)
+        for i, (f, s) in enumerate(zip(frees.tolist(), srcs.tolist())):
+            assert s == -1 or s in self.live, "a node was started from a snapshot that is not live"
+            self.warm += s >= 0
+            self.cold += s < 0
+            if f and len(self.live) < self.capacity:
+                dst[i] = self.next; self.live.add(self.next); self.next += 1; self.handed += 1
+        return lb, br, dst
+
+    def bnb_snap_release(self, slots):
+        for s in list(slots):
+            assert s in self.live, "a slot was released twice (or never handed out)"
+            self.live.discard(s)
+
+
+def _bnb_warm_worker(rank, world, port, out):
+    import torch.distributed as dist
+    import partls_amd
+    pls = partls_amd.package()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    X, y, P = _bnb_problem()
+    fake = _FakeSnapCtx(X, y, P)
+    res = pls.dist.bnb_search_warm(fake, P.shape[1] + 1, rank=rank, world=world, batch=4)
+    out[rank] = (res, len(fake.live), fake.handed, fake.warm, fake.cold)
+    dist.destroy_process_group()
+
+
+def test_bnb_search_warm_protocol_single_and_gloo_world2(partls, oracle):
+    """bnb_search_warm (nodes dealt to the rank that holds their parent's snapshot): same optimum as the cold search and the oracle;
+    the snapshot protocol is sound — no slot used after release, none released twice, none leaked at the end of a complete search —
+    with one rank, with a pool too small for the frontier, and with 2 gloo ranks (where both ranks end up owning subtrees)."""
+    import torch.multiprocessing as mp
+    X, y, P = _bnb_problem()
+    ref = oracle.fit_bnb(X, y, P)
+    cold = partls.dist.bnb_search(_oracle_bound_fn(X, y, P), P.shape[1] + 1, batch=4)
+    for cap in (10_000, 3):
+        fake = _FakeSnapCtx(X, y, P, capacity=cap)
+        mu, pat, free, bounded = partls.dist.bnb_search_warm(fake, P.shape[1] + 1, batch=4)
+        assert abs(mu - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and (pat, free) == (cold[1], cold[2])
+        assert len(fake.live) == 0 and fake.handed > 0 and fake.warm > 0          # every snapshot was returned; warm starts happened
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_bnb_warm_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(2):
+        (mu, pat, free, bounded), live, handed, warm, cold_n = out[r]
+        assert (pat, free) == (cold[1], cold[2]) and abs(mu - cold[0]) <= 1e-12 * max(1.0, cold[0])
+        assert live == 0 and warm > 0                                             # both ranks own snapshots and use them
+    assert out[0][0][3] == out[1][0][3]

@@ -226,3 +226,20 @@ def test_alt_and_bnb_take_more_groups_than_opt_can_enumerate(partls, oracle):
     with pytest.raises(partls.PartlsError) as ei:
         partls.fit(partls.BnB, X, y, Pbig)
     assert ei.value.status == partls.lowlevel.ERR_UNSUPPORTED
+
+
+def test_bnb_search_warm_through_the_snapshot_abi(partls, oracle):
+    """dist.bnb_search_warm on the real context (partls_bnb_snap_begin / _bound_snap / _snap_release): the host-driven search with
+    snapshot slots equals the in-library search (same optimum, same node count for the same batch size) and the oracle."""
+    X, y, P = _branching_problem(seed=9, D=40, K=7)
+    ref = oracle.fit_bnb(X, y, P)
+    ctx = partls.Context(0)
+    ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    mu_lib, pat_lib, free_lib, n_lib = ctx.bnb_search(0)
+    mu, pat, free, n = partls.dist.bnb_search_warm(ctx, P.shape[1] + 1, batch=1024)
+    cold = partls.dist.bnb_search(ctx.bnb_bound, P.shape[1] + 1)
+    a, b, t, opt = ctx.bnb_leaf(pat, free)
+    ctx.close()
+    assert abs(mu - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(mu - mu_lib) <= 1e-12 * mu_lib and abs(mu - cold[0]) <= 1e-10 * mu
+    assert (pat, free) == (pat_lib, free_lib) and n == n_lib and n > 20
+    assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])

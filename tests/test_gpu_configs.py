@@ -279,3 +279,49 @@ def test_grid_barrier_timeout_falls_back_to_one_workgroup(partls, oracle, monkey
     assert abs(opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
     np.testing.assert_allclose(a, ref["alpha"], atol=1e-6)
     assert 2.0 * iters <= dt < 4.0 * iters + 5.0, dt                      # one ~2 s timeout per alpha-step, not one per workgroup
+
+
+def _bnb_warm_gpu_worker(rank, world, port, out):
+    import numpy as np
+    import torch.distributed as dist
+    import partls_amd
+    pls = partls_amd.package()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(17)
+    N, D, K = 500, 48, 8
+    X = rng.standard_normal((N, D)); y = X @ rng.standard_normal(D) + 0.2 * rng.standard_normal(N)
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    ctx = pls.Context(0)                                         # both ranks share device 0: each has its own snapshot pool
+    ctx.opt_prepare(X, y, P, 0.0, pls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    res = pls.dist.bnb_search_warm(ctx, K + 1, rank=rank, world=world, batch=16)
+    a, b, t, opt = ctx.bnb_leaf(res[1], res[2])
+    out[rank] = (res, opt)
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_bnb_search_warm_two_ranks_on_one_device(partls, oracle):
+    """dist.bnb_search_warm with 2 gloo ranks that share device 0 (each with its own context and snapshot pool): nodes are dealt to the
+    rank that holds the parent's snapshot, surplus goes cold to the other — same optimum and node count on both ranks, same as the
+    in-library search and the oracle."""
+    import socket
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(17)
+    N, D, K = 500, 48, 8
+    X = rng.standard_normal((N, D)); y = X @ rng.standard_normal(D) + 0.2 * rng.standard_normal(N)
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    ref = oracle.fit_bnb(X, y, P)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctxm = mp.get_context("spawn")
+    out = ctxm.Manager().dict()
+    procs = [ctxm.Process(target=_bnb_warm_gpu_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    (mu0, pat0, free0, n0), opt0 = out[0]
+    (mu1, pat1, free1, n1), opt1 = out[1]
+    assert (pat0, free0, n0) == (pat1, free1, n1) and mu0 == mu1 and n0 > 30
+    assert abs(opt0 - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(mu0 - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])

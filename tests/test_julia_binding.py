@@ -54,6 +54,7 @@ def test_patch_serialises_the_shared_context():
 _C_FOR_CTYPES = {
     "partls_ctx*": {C.c_void_p}, "partls_ctx**": {C.POINTER(C.c_void_p)},
     "partls_multi*": {C.c_void_p}, "partls_multi**": {C.POINTER(C.c_void_p)},
+    "partls_frontier*": {C.c_void_p}, "partls_frontier**": {C.POINTER(C.c_void_p)},
     "double*": {C.POINTER(C.c_double), C.c_void_p}, "int64_t*": {C.POINTER(C.c_int64), C.c_void_p},
     "uint64_t*": {C.POINTER(C.c_uint64)}, "int32_t*": {C.POINTER(C.c_int32)}, "int*": {C.POINTER(C.c_int)},
     "double": {C.c_double}, "int64_t": {C.c_int64}, "uint64_t": {C.c_uint64}, "uint32_t": {C.c_uint32}, "int": {C.c_int},

@@ -20,6 +20,8 @@ JULIA_FOR_C = {
     "partls_ctx**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "partls_multi*": {"Ptr{Cvoid}"},
     "partls_multi**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "partls_frontier*": {"Ptr{Cvoid}"},
+    "partls_frontier**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "double*": {"Ptr{Float64}", "Ref{Float64}"},
     "int64_t*": {"Ptr{Int64}", "Ref{Int64}"},
     "uint64_t*": {"Ptr{UInt64}", "Ref{UInt64}"},
