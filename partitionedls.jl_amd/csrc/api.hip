@@ -181,7 +181,7 @@ static hipError_t launch_any_sweep(partls_ctx *c, SweepParams &p, int grid)
         return launch_sweep_blk(p, c->T, grid, c->stream);
     }
     p.T0 = c->Tfull.as<double>();
-    return launch_sweep_generic(p, grid, c->stream);
+    return c->knobs.eager_generic ? launch_sweep_generic(p, grid, c->stream) : launch_sweep_lazy(p, grid, c->stream);
 }
 
 void opt_codes(const partls_ctx *c, uint64_t pattern, std::vector<int8_t> &codes)
@@ -680,6 +680,7 @@ try {
     if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
+    c->knobs.eager_generic = getenv("PARTLS_EAGER_GENERIC") != nullptr;
     c->knobs.bnb_cold = getenv("PARTLS_BNB_COLD") != nullptr;
     if (const char *e = getenv("PARTLS_BNB_BATCH")) c->knobs.bnb_batch = atoi(e);
     if (const char *e = getenv("PARTLS_BNB_POOL_MB")) c->knobs.bnb_pool_mb = atoi(e);

@@ -100,7 +100,8 @@ __device__ __forceinline__ bool ref_index_less(unsigned long long a, unsigned lo
     return top >= 0 && !((a >> at) & 1ULL);
 }
 
-hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);
+hipError_t launch_sweep_generic(const SweepParams &p, int grid, hipStream_t s);   // tableau in global memory, every block applied at once
+hipError_t launch_sweep_lazy(const SweepParams &p, int grid, hipStream_t s);      // ... updates deferred (sweep_lazy.hip): the n > 320 path
 hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s);
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 320)
 bool       sweep_reg_supported(int n);

@@ -53,6 +53,7 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    bool eager_generic = false;  // PARTLS_EAGER_GENERIC: n > 320 on sweep_generic.hip (every block applied to the whole tableau) instead of sweep_lazy.hip (A/B tests)
     int bnb_batch = 1024;        // PARTLS_BNB_BATCH: nodes bounded per device batch of the BnB search
     int bnb_pool_mb = 16384;     // PARTLS_BNB_POOL_MB: cap of the tableau-snapshot pool of the BnB search (warm-started node bounds)
     bool bnb_cold = false;       // PARTLS_BNB_COLD: every BnB node from the fresh tableau (A/B tests)

@@ -1,0 +1,575 @@
+// sweep_lazy.hip — sign-pattern sweep beyond the register kernel (n > 320): the tableau in global memory, its updates DEFERRED.
+//
+// Same algorithm, same decisions and same SweepParams as sweep_generic.hip (block principal pivoting on the symmetric
+// principal-pivot tableau, Opt.jl:87-90 per pattern; node mode for BnB / Alt), one workgroup per Gray-code chain.  What differs is
+// where the bytes go.  sweep_generic.hip applies every block of <= 16 pivots to the whole (n+1)^2 / 2 triangle at once: 2 x 0.47 MB
+// through the memory system per block at n = 341 for ~0.7 MFLOP of work — it is bound by that traffic (1.05 M solves/s at D = 340).
+// But a block only ever READS m columns of the tableau (its pivot columns) and the rhs column.  So here
+//   * the rhs column q (and the objective corner) lives in LDS and follows every block at once;
+//   * the rank-1 terms of a block (z_s = pivot column s as of its own step, 1/d_s) are appended to a PENDING list in LDS (R terms);
+//   * a pivot column k is MATERIALISED on demand:  T[i][k] = base[i][k] - sum_{pending t >= max(ts_i, ts_k)} z_t[i] z_t[k] / d_t ;
+//   * the rows / columns of the pivoted variables, which a block REPLACES (T_ik = T_ik / |d|, T_kk = -1/d) rather than updates, are
+//     written to the base image at once (2 m n entries), and ts_k = "terms up to here are already in row / column k of the base";
+//   * only when the list is full is the base image brought up to date: ONE pass with a rank-R update (v_mfma_f64_16x16x4 on 16 x 16
+//     tiles of the upper triangle, the ts masks folded into the operands) — once per ~R pivots instead of once per block.
+// Bytes per pivot drop by R / (pivots per block) (~6x at n = 341: R = 34, blocks of 5.7), and the pass itself runs on the matrix
+// pipe with 16 x fewer LDS operand reads than the FMA form.  DESIGN.md §4 "Beyond n = 320".
+#include "gj_panel.h"
+#include <cstdlib>
+
+namespace partls {
+
+static constexpr int LZ_MAXWORDS = 16;      // n <= 1024
+static constexpr int LZ_MAXR = 64;          // rows of the LDS pool at most
+#ifndef LZ_MIN_SPLIT
+#define LZ_MIN_SPLIT 6                      // a block is cut short to fill the pool when at least this many pivots still fit
+#endif
+
+typedef double lz_double4 __attribute__((ext_vector_type(4)));
+
+#ifndef LZ_ABL
+#define LZ_ABL 0     // ablations of the flush (timing only, wrong results): 1 no stores, 2 no loads, 3 no MFMAs
+#endif
+#ifdef PARTLS_LZ_NT
+#define LZ_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define LZ_LOAD(p) (*(p))
+#endif
+#ifdef PARTLS_LZ_STAMPS     // diagnostic build: cycles of thread 0 of workgroup 0 per phase, printed at the end
+#define LZ_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); lz_cyc[slot] += now_ - lz_last; lz_last = now_; ++lz_cnt[slot]; } while (0)
+#else
+#define LZ_STAMP(slot) do { } while (0)
+#endif
+#ifdef PARTLS_LZ_STAMPS
+#define LZ_STK lz_cyc
+#else
+#define LZ_STK nullptr
+#endif
+
+__device__ __forceinline__ int lz_sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
+
+// entry (i, k) of the stored upper triangle
+__device__ __forceinline__ size_t lz_tri(int i, int k, int ld) { return i <= k ? (size_t)i * ld + k : (size_t)k * ld + i; }
+
+// The base image brought up to date: T[i][c] -= sum_t z_t[i] z_t[c] / d_t over the pending terms, for the upper triangle (c >= i), rows
+// and columns < n (column n, the rhs, lives in LDS).  No masks: entries of a term that must not be applied any more (row / column
+// replaced since — see the kernel) were zeroed in LDS when that happened, rejected pivots and the padding up to a multiple of 4 have
+// 1/d = 0.  Work item = a strip of FOUR 16 x 16 tiles of one tile row (four independent accumulators per wave, shared A fragment),
+// k = 4 pending terms per MFMA: A[i][k] = -z_t[i] / d_t, B[k][c] = z_t[c]; C/D map: col = lane & 15, row = (lane >> 4) + 4 reg.
+// The strip's 16 loads are issued FIRST and only consumed after the MFMAs (the products are summed from zero and added to the loaded
+// entries at the end), so the memory latency of a strip hides behind its own arithmetic without any cross-iteration pipelining (a
+// prefetch of the next strip into a second register set ends in s_waitcnt vmcnt(0) in front of the MFMAs: the compiler cannot count
+// across the loop's back edge).  Diagonal tiles are updated whole (their lower halves are never read).  Floor: n^2 flop per pending
+// term on a 0.3 TFLOP/s CU — ~1k cycles per pivot at n = 341.
+template <int NT>
+__device__ __forceinline__ void lz_flush(double *T, int ld_, int n_, const double *Zp, const double *dp, int Rcur_, int tid, unsigned long long *stk = nullptr)
+{
+#ifdef PARTLS_LZ_STAMPS
+    unsigned long long fl_t0 = __builtin_readcyclecounter(), fl_k = 0, fl_l = 0;
+#endif
+    const int ld = __builtin_amdgcn_readfirstlane(ld_), n = __builtin_amdgcn_readfirstlane(n_);
+    const int Rcur = __builtin_amdgcn_readfirstlane(Rcur_);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fk = lane >> 4;
+    const int NTl = (n + 15) >> 4;                                          // tile rows / columns
+    const int ksteps = (Rcur + 3) >> 2;
+    constexpr int NW = NT / 64;
+    int nitems = 0;
+    for (int I = 0; I < NTl; ++I) nitems += (NTl - I + 3) >> 2;
+    for (int w = wave; w < nitems; w += NW) {
+        int I = 0, rem = w;
+        for (;;) { const int c = (NTl - I + 3) >> 2; if (rem < c) break; rem -= c; ++I; }
+        const int J0 = I + 4 * rem;
+        // EDGE: the strip reaches beyond row / column n - 1 (last tile row / column): clamped loads and operand reads (out-of-range results
+        // are computed on valid data and not stored).  Interior strips — most — run without any of that.
+        auto strip = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
+            const int ra = I * 16 + fr, ra_c = (EDGE && ra >= n) ? n - 1 : ra;
+            int cb[4], cb_c[4], off[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cb[q] = (J0 + q) * 16 + fr; cb_c[q] = (EDGE && cb[q] >= n) ? n - 1 : cb[q]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = I * 16 + fk + 4 * r; off[r] = ((EDGE && row >= n) ? n - 1 : row) * ld; }
+            lz_double4 old[4], acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { old[q][r] = T[off[r] + cb_c[q]]; acc[q][r] = 0.0; }
+            }
+#ifdef PARTLS_LZ_STAMPS
+            fl_l += __builtin_readcyclecounter() - fl_t0; fl_t0 = __builtin_readcyclecounter();
+#endif
+            // operands of k-step ks: term t = 4 ks + fk; the reads of step ks + 1 are in flight under the MFMAs of step ks
+            const double *zr = Zp + fk * ld;
+            const double *dr = dp + fk;
+            double za = zr[ra_c], zb[4], di = dr[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zb[q] = zr[cb_c[q]];
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const double a = -za * di;
+                double b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = zb[q];
+                zr += 4 * ld; dr += 4;                                      // one step beyond the last: rows of the pool / qs — read, never used
+                za = zr[ra_c]; di = dr[0];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zb[q] = zr[cb_c[q]];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[q], acc[q], 0, 0, 0);
+            }
+#ifdef PARTLS_LZ_STAMPS
+            asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+            fl_k += __builtin_readcyclecounter() - fl_t0; fl_t0 = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!EDGE || (cb[q] < n && I * 16 + fk + 4 * r < n)) T[off[r] + cb_c[q]] = old[q][r] + acc[q][r];
+                }
+            }
+        };
+        if (I * 16 + 16 <= n && (J0 + 4) * 16 <= n) strip(std::false_type{});
+        else strip(std::true_type{});
+    }
+#ifdef PARTLS_LZ_STAMPS
+    fl_l += __builtin_readcyclecounter() - fl_t0;
+    if (stk) { stk[6] += fl_k; stk[7] += fl_l; }
+#endif
+}
+
+// The block's panel, eliminated in LDS — the recurrence of gj_panel_eliminate (gj_panel.h: same operations in the same order on every
+// row, same acceptance rule, same outputs: BIT-IDENTICAL results), reorganised so that it needs three barriers per BLOCK instead of two
+// per PIVOT.  Row i of the panel only ever needs, at step s, the entries of pivot column s at the m pivot rows (u_s[j]), d_s and 1/d_s:
+// the recurrence restricted to the m pivot ROWS is self-contained.  So
+//   phase 1: ONE wave runs those m rows (lane j = pivot row k_j; a step writes the lanes' entries of column s to the table and reads
+//            them back as LDS broadcasts) and leaves the table (u_s[j], d_s, 1/d_s) in LDS — m dependent steps, no barrier;
+//   phase 2: every other row runs its m steps against the table — no communication at all.
+// MT (8 or 16) is the compiled panel width: columns / lanes m..MT-1 are zero and stay zero, so no step carries per-column guards.
+// The leave-one-out veto (an entering pivot is refused when ANY basic row j has T_jk^2 eps >= d_k) is only known after phase 2: the
+// steps are taken optimistically, every row raises the flag of a step it would have vetoed, and in the rare case that one is raised
+// the block is redone from its (still untouched) panel image with that step marked "refused" — exactly what the step-by-step form does.
+// tab: [GJ_MB][GJ_MB] u, [GJ_MB][GJ_MB] final pivot rows, [GJ_MB] d, [GJ_MB] 1/d;  red: [GJ_MB] veto flags.
+template <int NT, int MT>
+__device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ dinv,
+                                                  double *__restrict__ tab, double *__restrict__ red, const int *__restrict__ ks, int m_,
+                                                  int ld_, uint8_t *__restrict__ s_basic, int myj, unsigned basm_, double piv_eps, int tid,
+                                                  unsigned long long *stk = nullptr)
+{
+#ifdef PARTLS_LZ_STAMPS
+    unsigned long long pt0 = __builtin_readcyclecounter();
+#define LZ_PSTAMP(i) do { if (stk) { const unsigned long long n_ = __builtin_readcyclecounter(); stk[i] += n_ - pt0; pt0 = n_; } } while (0)
+#else
+#define LZ_PSTAMP(i) do { } while (0)
+#endif
+    const int m = __builtin_amdgcn_readfirstlane(m_), ld = __builtin_amdgcn_readfirstlane(ld_);
+    const unsigned basm = (unsigned)__builtin_amdgcn_readfirstlane((int)basm_);   // bit s: pivot s LEAVES the basis (no acceptance test)
+    const int lane = tid & 63;
+    const bool has_row = tid < ld;
+    const bool var_row = tid < ld - 1;                                   // the last row is the rhs: no variable, never vetoes
+    double *__restrict__ tabU = tab, *__restrict__ tabF = tab + GJ_MB * GJ_MB, *__restrict__ tabD = tabF + GJ_MB * GJ_MB,
+           *__restrict__ tabI = tabD + GJ_MB;
+    const int krow = ks[lane < m ? lane : 0];                            // phase 1: the pivot row this lane of wave 0 stands for
+    unsigned skip = 0;                                                   // steps refused by the veto (found in earlier trips)
+    unsigned accm = 0;
+    LZ_PSTAMP(8);
+    double pv[MT];                                                       // phase 2: this thread's own row
+    // phase 1 runs on the LAST wave (at n <= 447 it owns no tableau row, so nobody waits for its phase 2), the other waves follow it step
+    // by step: `prog` (LDS) = steps whose table row is complete; a row's step s starts as soon as prog > s.  The last wave takes its own
+    // rows (if any) when it is through.  Every wait is on the last wave only, which never waits: no cycle.
+    constexpr int P1W = NT / 64 - 1;
+    const bool p1wave = (tid >> 6) == P1W;
+    int *prog = reinterpret_cast<int *>(red + GJ_MB);                    // red: [GJ_MB] flags, then this word
+    for (;;) {
+        if (tid < GJ_MB) red[tid] = 0.0;
+        if (tid == 0) __hip_atomic_store(prog, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        if (p1wave) {                                                    // ---- phase 1 -------------------------------------------
+            double pp[MT];
+#pragma unroll
+            for (int j = 0; j < MT; ++j) pp[j] = (j < m && lane < m) ? Pn[j * ld + krow] : 0.0;
+#pragma unroll
+            for (int s = 0; s < MT; ++s) {
+                if (s >= m) break;                                       // uniform
+                const double zi = pp[s];
+                if (lane < MT) tabU[s * GJ_MB + lane] = zi;              // column s at the pivot rows; read back below as broadcasts
+                double u[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) u[j] = tabU[s * GJ_MB + j];
+                const double d = u[s];
+                const bool bas = (basm >> s) & 1u, skp = (skip >> s) & 1u;
+                const bool pre = !skp && (bas || d > piv_eps);           // the same in every lane
+                if (!bas && !skp && lane < m && lane != s && (zi * zi) * piv_eps >= d) red[s] = 1.0;
+                const double inv = pre ? gj_rcp(d) : 0.0, ainv = fabs(inv);    // refused: 1/d = 0 makes the step a no-op below
+                if (lane == 0) { tabD[s] = d; tabI[s] = inv; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(prog, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane < m) Zn[s * ld + krow] = zi;
+                const double mi = -zi * inv;
+                const bool piv = pre && lane == s;
+#pragma unroll
+                for (int j = 0; j < MT; ++j) if (j != s) pp[j] = fma(mi, u[j], pp[j]);
+                pp[s] = pre ? zi * ainv : zi;
+                if (piv) {                                               // the pivot row itself
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) if (j != s) pp[j] = u[j] * ainv;
+                    pp[s] = -inv;
+                }
+            }
+            if (lane < m) {                                              // the pivot rows' final entries wait in LDS until the flags are known
+#pragma unroll
+                for (int j = 0; j < MT; ++j) tabF[lane * GJ_MB + j] = pp[j];
+            }
+        }
+        LZ_PSTAMP(9);
+        if (has_row && myj < 0) {                                        // ---- phase 2: all other rows ---------------------------
+#pragma unroll
+            for (int j = 0; j < MT; ++j) pv[j] = (j < m) ? Pn[j * ld + tid] : 0.0;
+#pragma unroll
+            for (int s = 0; s < MT; ++s) {
+                if (s >= m) break;                                       // uniform
+                if (!p1wave) {                                           // (uniform) wait for the table row of step s
+                    int spins = 0;
+                    while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                const double inv = tabI[s];                              // 0: refused — the row does not move
+                const double zi = pv[s];
+                if (!((basm >> s) & 1u) && var_row && (zi * zi) * piv_eps >= tabD[s]) red[s] = 1.0;   // only counted when 1/d != 0
+                Zn[s * ld + tid] = zi;
+                const double mi = -zi * inv;
+#pragma unroll
+                for (int j = 0; j < MT; ++j) if (j != s) pv[j] = fma(mi, tabU[s * GJ_MB + j], pv[j]);
+                pv[s] = (inv != 0.0) ? zi * fabs(inv) : zi;
+            }
+        }
+        LZ_PSTAMP(11);
+        __syncthreads();
+        LZ_PSTAMP(12);
+        const bool live = lane < m && tabI[lane] != 0.0;
+        const unsigned veto = (unsigned)__ballot(live && red[lane] != 0.0);
+        accm = (unsigned)__ballot(live);
+        if (veto == 0) {
+            // the final panel: rows / columns of the pivoted variables
+            if (has_row && myj < 0) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) if (j < m) Pn[j * ld + tid] = pv[j];
+            }
+            if (p1wave && lane < m) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) if (j < m) Pn[j * ld + krow] = tabF[lane * GJ_MB + j];
+                if (live) s_basic[krow] ^= 1;                            // accepted pivots change sides
+                dinv[lane] = tabI[lane];
+            }
+            break;
+        }
+        skip |= veto & (0u - veto);                                      // the first refused step changes every later one: one at a time
+        __syncthreads();
+    }
+    LZ_PSTAMP(13);
+    __syncthreads();
+    LZ_PSTAMP(14);
+    return __popc(accm);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, int rows)
+{
+    const int n = p.n, ld = n + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    extern __shared__ double smem[];
+    // ONE pool of `rows` tableau-row images: the pending terms grow from row 0, the panel of the current block (m <= mb columns) sits in
+    // the last m rows — a block fits while Rcur + 2 m <= rows (a fixed mb-row panel would idle half its rows on the typical block)
+    double *pool = smem;                                          // [rows + 4][ld]  (+4: the flush reads one k-step beyond the last)
+    double *Zp = pool;                                            // pending terms: column s as of its own step
+    double *qs = pool + (size_t)(rows + 4) * ld;                  // [ld] the rhs column, up to date; qs[n] = objective^2
+    double *dp = qs + ld;                                         // [rows + GJ_MB] 1/d of the pending terms (0: rejected, never applied)
+    double *Cj = dp + rows + GJ_MB;                               // [rows + 4][GJ_MB] z_t[k_j] / d_t of the current block's pivot columns
+    double *tab = Cj + (size_t)(rows + 4) * GJ_MB;                      // 2 [GJ_MB][GJ_MB] + 2 [GJ_MB]: the panel's pivot-row tables (lz_panel_eliminate)
+    double *red = tab + 2 * GJ_MB * GJ_MB + 2 * GJ_MB;                // [16] veto flags + the panel's progress word
+    uint8_t *s_basic = reinterpret_cast<uint8_t *>(red + 18);     // n bytes
+    uint8_t *s_blocked = s_basic + n;                             // n bytes
+    int8_t *rowj = reinterpret_cast<int8_t *>(s_blocked + n);    // [ld] row i is pivot row rowj[i] of the current block (-1: none)
+    __shared__ unsigned s_basm;
+    __shared__ unsigned long long s_inf[LZ_MAXWORDS];
+    __shared__ int s_viol[LZ_MAXWORDS * 64];
+
+    double *T = p.scratch + (size_t)blockIdx.x * (size_t)ld * (size_t)ld;
+    const int nwords = (n + 63) >> 6;
+    const bool has_row = tid < ld;
+
+    double best_obj = __builtin_inf();
+    long long best_pat = -1;
+    double second_obj = __builtin_inf();
+    long long second_pat = -1;
+    unsigned long long npiv = 0, nunconv = 0;
+
+#ifdef PARTLS_LZ_STAMPS
+    unsigned long long lz_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lz_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_last = __builtin_readcyclecounter();
+#endif
+    for (int i = tid; i < (rows + 4) * ld; i += NT) pool[i] = 0.0;   // everything the flush may read is finite from the start
+    for (int i = tid; i < rows + GJ_MB; i += NT) dp[i] = 0.0;
+    for (int i = tid; i < ld; i += NT) rowj[i] = -1;
+
+    const int64_t total = p.g_end - p.g_begin;
+    const int64_t nchains = (total + p.chain_len - 1) / p.chain_len;
+
+    for (int64_t chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+        const int64_t g0 = p.g_begin + chain * p.chain_len;
+        const int64_t g1 = (g0 + p.chain_len < p.g_end) ? g0 + p.chain_len : p.g_end;
+        for (int i = tid >> 6; i < n; i += NT / 64)                  // upper triangle only, whole 64-chunks
+            for (int c = (i & ~63) + lane; c < n; c += 64) T[(size_t)i * ld + c] = p.T0[(size_t)i * ld + c];
+        if (has_row) qs[tid] = p.T0[(size_t)tid * ld + n];
+        for (int i = tid; i < n; i += NT) { s_basic[i] = 0; s_blocked[i] = 0; }
+        int Rcur = 0;                                                         // pending terms (uniform)
+        __threadfence_block();
+        __syncthreads();
+        LZ_STAMP(0);                                                          // chain start
+
+        for (int64_t g = g0; g < g1; ++g) {
+            uint64_t pat = (uint64_t)g ^ ((uint64_t)g >> 1);
+            const int8_t *code = p.node_code ? p.node_code + ((size_t)chain * p.chain_len + (size_t)(g - g0)) * p.node_ld : nullptr;
+            if (code) pat = (uint64_t)chain;
+            for (int i = tid; i < n; i += NT) s_blocked[i] = 0;
+            __syncthreads();
+            int ninf_best = n + 1, patience = 3, rounds = 0;
+            bool progress = false;
+            for (;;) {
+                if (progress) {                                    // rejections hold for the basis they were tested against only
+                    for (int i = tid; i < n; i += NT) s_blocked[i] = 0;
+                    __syncthreads();
+                }
+                progress = false;
+                // ---- KKT scan of the rhs column (LDS); every violator finds its own place in the list ------------------
+                bool bad = false;
+                if (tid < n) {
+                    const int v = tid;
+                    const double q = qs[v];
+                    const int cd = code ? (int)code[v] : 0;
+                    const int f = code ? (cd == 2 ? 0 : cd) : lz_sign_of_var(p.mask[v], pat);
+                    const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
+                    if (cd == 2) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);     // free: stationarity only
+                    else if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
+                    else bad = (fq > p.tol) && !s_blocked[v];
+                }
+                const unsigned long long bal = __ballot(bad);
+                if (lane == 0 && (tid >> 6) < nwords) s_inf[tid >> 6] = bal;
+                __syncthreads();
+                int count = 0, before = 0;
+                for (int w = 0; w < nwords; ++w) {
+                    const int c = __popcll(s_inf[w]);
+                    if (w < (tid >> 6)) before += c;
+                    count += c;
+                }
+                if (count == 0) break;
+                bool all;
+                if (count < ninf_best) { ninf_best = count; patience = 3; all = true; }
+                else if (patience > 0) { --patience; all = true; }
+                else all = false;                                  // backup rule: single pivot, largest index
+                if (++rounds > p.max_rounds) { ++nunconv; break; }
+                if (bad) {                                         // ascending list; the backup rule keeps only the last one
+                    const int pos = before + __popcll(bal & ((1ULL << lane) - 1ULL));
+                    if (all) s_viol[pos] = tid;
+                    else if (pos == count - 1) s_viol[0] = tid;
+                }
+                __syncthreads();
+                const int nv = all ? count : 1;
+                LZ_STAMP(1);                                                  // scan + violator list
+                for (int b0 = 0; b0 < nv;) {
+                    int m = (nv - b0 < mb) ? nv - b0 : mb;
+                    if (Rcur + 2 * m > rows) {
+                        // no room for m more terms below an m-row panel.  A smaller block that fills the pool first (one more block,
+                        // but ~40 % more terms per pass over the base image), or the pass now
+                        const int m2 = (rows - Rcur) >> 1;
+                        if (m2 >= LZ_MIN_SPLIT) m = m2;
+                        else {
+                            if (tid < 4) dp[Rcur + tid] = 0.0;                // padding of the last k-step
+                            __syncthreads();
+                            #ifdef PARTLS_LZ_STAMPS
+                            lz_flush<NT>(T, ld, n, Zp, dp, Rcur, tid, lz_cyc);
+#else
+                            lz_flush<NT>(T, ld, n, Zp, dp, Rcur, tid);
+#endif
+                            __threadfence_block();
+                            __syncthreads();
+                            Rcur = 0;
+                            LZ_STAMP(2);                                      // flush
+                        }
+                    }
+                    m = __builtin_amdgcn_readfirstlane(m);
+                    const int *ks = s_viol + b0;
+                    double *Pn = pool + (size_t)(rows - m) * ld;   // the block's panel: its pivot columns, all rows
+                    // ---- coefficients of the pending terms for this block's columns (rows padded with zeros to a multiple of 4) ------
+                    for (int e = tid; e < ((Rcur + 3) & ~3) * GJ_MB; e += NT) {
+                        const int t = e / GJ_MB, j = e % GJ_MB;
+                        Cj[e] = (j < m && t < Rcur) ? Zp[(size_t)t * ld + ks[j]] * dp[t] : 0.0;
+                    }
+                    if (tid < 64) {                                // who is a pivot row of this block, and which pivots leave the basis
+                        const bool mine = tid < m;
+                        const int k = ks[mine ? tid : 0];
+                        if (mine) rowj[k] = (int8_t)tid;
+                        const unsigned long long bm = __ballot(mine && s_basic[k] != 0);
+                        if (tid == 0) s_basm = (unsigned)bm;
+                    }
+                    __syncthreads();
+                    const int myj = has_row ? (int)rowj[tid] : -1;
+                    const unsigned basm = s_basm;
+                    // ---- the block's pivot columns: base entries (in flight) minus the pending terms ------------------
+                    // P[j][i] = base[i][k_j] - sum_t z_t[i] (z_t[k_j] / d_t): a (rows x terms) x (terms x 16) product on the matrix pipe, 16
+                    // rows per MFMA tile (A[i][k] = z_t[i], B[k][j] = Cj[t][j]); C/D map: column j = lane & 15, row = (lane >> 4) + 4 reg.
+                    {
+                        constexpr int TPW = 3;                     // tiles per wave and turn: their base loads are all in flight together
+                        const int fr = lane & 15, fk = lane >> 4, wv = tid >> 6;
+                        const int ksteps = (Rcur + 3) >> 2, NTl = (n + 15) >> 4;
+                        const int kcol = ks[fr < m ? fr : 0];
+                        for (int t0 = wv * TPW; t0 < NTl; t0 += (NT / 64) * TPW) {
+                            double base[TPW][4];
+                            lz_double4 acc[TPW];
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = (t0 + u) * 16 + fk + 4 * r, rc = row < n ? row : n - 1;
+                                    base[u][r] = (fr < m) ? LZ_LOAD(&T[lz_tri(rc, kcol, ld)]) : 0.0;
+                                    acc[u][r] = 0.0;
+                                }
+                            }
+                            int ra[TPW];
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) { const int x = (t0 + u) * 16 + fr; ra[u] = x < n ? x : n - 1; }
+                            const double *zr = Zp + fk * ld, *cr = Cj + fk * GJ_MB + fr;
+                            for (int q = 0; q < ksteps; ++q) {
+                                const double b = cr[0];
+#pragma unroll
+                                for (int u = 0; u < TPW; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[ra[u]], b, acc[u], 0, 0, 0);
+                                zr += 4 * ld; cr += 4 * GJ_MB;
+                            }
+#pragma unroll
+                            for (int u = 0; u < TPW; ++u) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int row = (t0 + u) * 16 + fk + 4 * r;
+                                    if (fr < m && row < n) Pn[(size_t)fr * ld + row] = base[u][r] - acc[u][r];
+                                }
+                            }
+                        }
+                        if (tid < m) Pn[(size_t)tid * ld + n] = qs[ks[tid]];         // row n of column k = entry k of the rhs column
+                    }
+                    __syncthreads();
+                    LZ_STAMP(3);                                              // gather + materialise
+                    double *Zn = Zp + (size_t)Rcur * ld, *dn = dp + Rcur;
+                    int acc_piv;
+                    if constexpr (NT <= 512) {
+                        acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, LZ_STK)
+                                         : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, LZ_STK);
+                    } else {                                                  // 128 VGPRs per thread: the step-by-step form (two barriers per pivot, few registers)
+                        acc_piv = gj_panel_eliminate<NT>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, p.piv_eps, tid);
+                    }
+                    LZ_STAMP(4);                                              // panel
+                    // ---- after the panel: rhs column, replaced rows / columns, bookkeeping -----------------------------
+                    const unsigned accm = (unsigned)__ballot(lane < m && dn[lane < m ? lane : 0] != 0.0);
+                    if (has_row) {
+                        if (myj >= 0) qs[tid] = Pn[(size_t)myj * ld + n];
+                        else {
+                            double a = qs[tid];
+                            for (int s = 0; s < m; ++s)
+                                if ((accm >> s) & 1u) a = fma(-Zn[(size_t)s * ld + tid] * dn[s], Zn[(size_t)s * ld + n], a);
+                            qs[tid] = a;
+                        }
+                    }
+                    if (tid < n) {
+                        // entry (k_a, k_b), a < b, is taken from panel column a: every entry of the base has exactly one writer
+                        for (int j = 0; j < m; ++j)
+                            if (myj < 0 || j <= myj) T[lz_tri(tid, ks[j], ld)] = Pn[(size_t)j * ld + tid];
+                    }
+                    // the rows / columns of the pivoted variables now hold ALL terms up to this block: what the pending terms (this
+                    // block's included) say about them must never be applied again — zero it where it is stored (the entries a
+                    // non-pivot row reads in the rhs update above are its own and entry n: not touched)
+                    for (int e = tid; e < (Rcur + m) * GJ_MB; e += NT) {
+                        const int t = e / GJ_MB, j = e % GJ_MB;
+                        if (j < m) Zp[(size_t)t * ld + ks[j]] = 0.0;
+                    }
+                    if (tid < m) {
+                        const int k = ks[tid];
+                        if (dn[tid] == 0.0) s_blocked[k] = 1;
+                        rowj[k] = -1;
+                    }
+                    Rcur += m;
+                    b0 += m;
+                    if (acc_piv) { npiv += (unsigned)acc_piv; progress = true; }
+                    __threadfence_block();
+                    __syncthreads();
+                    LZ_STAMP(5);                                              // rhs, replaced rows / columns
+                }
+            }
+            const double obj2 = qs[n];
+            const double obj = sqrt(obj2 > 0.0 ? obj2 : 0.0);
+            if (p.all_opt && tid == 0) p.all_opt[pat] = obj;
+            if (obj < best_obj || (obj == best_obj && best_pat >= 0 && ref_index_less(pat, (unsigned long long)best_pat, p.rbit.gbit))) {
+                second_obj = best_obj; second_pat = best_pat;
+                best_obj = obj; best_pat = (long long)pat;
+            } else if (obj < second_obj) { second_obj = obj; second_pat = (long long)pat; }
+            if (p.node_piv && code && tid == 0) {
+                unsigned *o = p.node_piv + 3 * ((size_t)chain * p.chain_len + (size_t)(g - g0));
+                o[0] = (unsigned)npiv; o[1] = 0; o[2] = 0;
+            }
+            __syncthreads();
+        }
+        if (p.node_sol) {
+            for (int i = tid; i < n; i += NT)
+                p.node_sol[(size_t)chain * p.node_ld + i] = s_basic[i] ? qs[i] : 0.0;
+            if (tid == 0) p.node_obj2[chain] = qs[n];
+        }
+        __syncthreads();
+    }
+#ifdef PARTLS_LZ_STAMPS
+    if (tid == 0 && blockIdx.x == 0)
+        printf("lazy stamps (cycles, count): start %llu %llu | scan %llu %llu | flush %llu %llu | materialise %llu %llu | panel %llu %llu | post %llu %llu | flush k-loops %llu other %llu | panel: setup %llu p1 %llu bar %llu p2 %llu bar %llu tail %llu end %llu | pivots %llu mb %d rows %d\n",
+               lz_cyc[0], lz_cnt[0], lz_cyc[1], lz_cnt[1], lz_cyc[2], lz_cnt[2], lz_cyc[3], lz_cnt[3], lz_cyc[4], lz_cnt[4], lz_cyc[5], lz_cnt[5], lz_cyc[6], lz_cyc[7], lz_cyc[8], lz_cyc[9], lz_cyc[10], lz_cyc[11], lz_cyc[12], lz_cyc[13], lz_cyc[14], npiv, mb, rows);
+#endif
+    if (tid == 0) {
+        p.best_obj[blockIdx.x] = best_obj;
+        p.best_pat[blockIdx.x] = best_pat;
+        if (p.second_obj) { p.second_obj[blockIdx.x] = second_obj; p.second_pat[blockIdx.x] = second_pat; }
+        if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
+        if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
+    }
+}
+
+// LDS plan for leading dimension ld: pivots per block and rows of the pool (pending terms + panel).  false: no plan fits (never for n <= 1023)
+bool lazy_plan(int ld, int *mb_out, int *rows_out, size_t *shmem_out)
+{
+    const size_t budget = (size_t)151 * 1024;
+    const size_t fixed = (size_t)ld * 8 /* qs */ + 4 * (size_t)ld * 8 /* read-ahead rows */ + 3 * (size_t)ld /* flags, rowj */ + (2 * GJ_MB * GJ_MB + 8 * GJ_MB + 18) * 8 + 64;
+    const size_t row = (size_t)ld * 8;
+    if (budget < fixed + 6 * (row + 8 + GJ_MB * 8)) return false;
+    int rows = (int)((budget - fixed) / (row + 8 + GJ_MB * 8));              // each row: z or panel column, 1/d, Cj
+    if (rows > LZ_MAXR) rows = LZ_MAXR;
+    int mb = rows / 3;
+    if (mb > GJ_MB) mb = GJ_MB;
+    if (mb < 2) mb = 2;
+    *mb_out = mb; *rows_out = rows;
+    *shmem_out = ((size_t)(rows + 4) * ld + ld + rows + GJ_MB + (size_t)(rows + 4) * GJ_MB + 2 * GJ_MB * GJ_MB + 2 * GJ_MB + 18) * 8 + 3 * (size_t)ld + 16;
+    return true;
+}
+
+template <int NT>
+static hipError_t launch_lazy_nt(const SweepParams &p, int grid, int mb, int rows, size_t shmem, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lazy_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sweep_lazy_kernel<NT>, dim3(grid), dim3(NT), shmem, s, p, mb, rows);
+    return hipGetLastError();
+}
+
+// one thread per tableau row in the panel: 512 threads up to n = 511 (half the waves at every barrier of the m panel steps), 1024 beyond
+hipError_t launch_sweep_lazy(const SweepParams &p, int grid, hipStream_t s)
+{
+    int mb = 0, rows = 0;
+    size_t shmem = 0;
+    if (!lazy_plan(p.n + 1, &mb, &rows, &shmem)) return hipErrorInvalidValue;
+    static const bool force1024 = getenv("PARTLS_LZ_1024") != nullptr;   // experiment
+    return (p.n + 1 <= 512 && !force1024) ? launch_lazy_nt<512>(p, grid, mb, rows, shmem, s) : launch_lazy_nt<1024>(p, grid, mb, rows, shmem, s);
+}
+
+}  // namespace partls
