@@ -905,8 +905,13 @@ try {
         if (chain_len < 16) chain_len = 16;                     // tiny ranges: fewer chains than CUs rather than chains of a few patterns
         }
     } else {
-        chain_len = 64;
-        while (chain_len > 16 && (total + chain_len - 1) / chain_len < 512) chain_len >>= 1;
+        // global-memory kernels (n > 320): a chain start costs ~n/2 pivots (the first pattern is solved from the empty basis) against ~25 per
+        // warm-started pattern, so chains are as long as still leaves every CU one (measured at D = 340, 2^16 / 2^18 patterns: 64 -> 3.79 /
+        // 4.17 M solves/s, 128 -> 3.90 / 4.37, 256 -> 4.01 / 4.46)
+        int ncu = 256;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+        chain_len = 256;
+        while (chain_len > 16 && (total + chain_len - 1) / chain_len < ncu) chain_len >>= 1;
     }
     if (chain_len < 1) chain_len = 1;
     const int64_t nchains = (total + chain_len - 1) / chain_len;

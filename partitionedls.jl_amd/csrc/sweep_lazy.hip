@@ -138,12 +138,29 @@ __device__ __forceinline__ void lz_flush(double *T, int ld_, int n_, const doubl
 #endif
 }
 
+__device__ __forceinline__ double lz_readlane(double v, int l)            // l: wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// acc += y[lane 16 (lane / 16) + g] * x   (gfx90a+; semantics and rate checked by tools/ubench/fmac_dpp.hip)
+__device__ __forceinline__ void lz_fmac_bcast(double &acc, double y, double x, int g)
+{
+    switch (g) {
+#define LZ_FB(G) case G: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #G " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y), "v"(x)); break;
+        LZ_FB(0) LZ_FB(1) LZ_FB(2) LZ_FB(3) LZ_FB(4) LZ_FB(5) LZ_FB(6) LZ_FB(7) LZ_FB(8) LZ_FB(9) LZ_FB(10) LZ_FB(11) LZ_FB(12) LZ_FB(13) LZ_FB(14) LZ_FB(15)
+#undef LZ_FB
+        default: break;
+    }
+}
+
 // The block's panel, eliminated in LDS — the recurrence of gj_panel_eliminate (gj_panel.h: same operations in the same order on every
 // row, same acceptance rule, same outputs: BIT-IDENTICAL results), reorganised so that it needs three barriers per BLOCK instead of two
 // per PIVOT.  Row i of the panel only ever needs, at step s, the entries of pivot column s at the m pivot rows (u_s[j]), d_s and 1/d_s:
 // the recurrence restricted to the m pivot ROWS is self-contained.  So
-//   phase 1: ONE wave runs those m rows (lane j = pivot row k_j; a step writes the lanes' entries of column s to the table and reads
-//            them back as LDS broadcasts) and leaves the table (u_s[j], d_s, 1/d_s) in LDS — m dependent steps, no barrier;
+//   phase 1: ONE wave runs those m rows (lane j = pivot row k_j; the u_s[j] of a step are DPP row broadcasts of the lanes' own entries)
+//            and leaves the table (u_s[j], d_s, 1/d_s) in LDS — m dependent steps, no barrier, no LDS round trip;
 //   phase 2: every other row runs its m steps against the table — no communication at all.
 // MT (8 or 16) is the compiled panel width: columns / lanes m..MT-1 are zero and stay zero, so no step carries per-column guards.
 // The leave-one-out veto (an entering pivot is refused when ANY basic row j has T_jk^2 eps >= d_k) is only known after phase 2: the
@@ -154,7 +171,7 @@ template <int NT, int MT>
 __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ dinv,
                                                   double *__restrict__ tab, double *__restrict__ red, const int *__restrict__ ks, int m_,
                                                   int ld_, uint8_t *__restrict__ s_basic, int myj, unsigned basm_, double piv_eps, int tid,
-                                                  unsigned long long *stk = nullptr)
+                                                  unsigned long long &nveto, unsigned long long *stk = nullptr)
 {
 #ifdef PARTLS_LZ_STAMPS
     unsigned long long pt0 = __builtin_readcyclecounter();
@@ -192,29 +209,31 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
             for (int s = 0; s < MT; ++s) {
                 if (s >= m) break;                                       // uniform
                 const double zi = pp[s];
-                if (lane < MT) tabU[s * GJ_MB + lane] = zi;              // column s at the pivot rows; read back below as broadcasts
-                double u[MT];
-#pragma unroll
-                for (int j = 0; j < MT; ++j) u[j] = tabU[s * GJ_MB + j];
-                const double d = u[s];
+                if (lane < MT) tabU[s * GJ_MB + lane] = zi;              // column s at the pivot rows: phase 2 reads it as broadcasts
+                const double d = lz_readlane(zi, s);
                 const bool bas = (basm >> s) & 1u, skp = (skip >> s) & 1u;
-                const bool pre = !skp && (bas || d > piv_eps);           // the same in every lane
+                const bool pre = !skp && (bas || d > piv_eps);           // uniform
                 if (!bas && !skp && lane < m && lane != s && (zi * zi) * piv_eps >= d) red[s] = 1.0;
                 const double inv = pre ? gj_rcp(d) : 0.0, ainv = fabs(inv);    // refused: 1/d = 0 makes the step a no-op below
                 if (lane == 0) { tabD[s] = d; tabI[s] = inv; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                // the LDS executes one wave's operations in order: the progress word cannot become visible before the table row written
+                // above it — no s_waitcnt needed, only the compiler must keep the order
+                asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(prog, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane < m) Zn[s * ld + krow] = zi;
-                const double mi = -zi * inv;
+                // row update  pp[j] = fma(-zi / d, u_j, pp[j])  with u_j = lane j's zi taken by DPP (v_fmac_f64_dpp row_newbcast: the pivot
+                // rows sit in lanes 0..15, one DPP row); the pivot row itself becomes u_j |1/d| = fma(u_j, |1/d|, 0): same instruction with
+                // its own multiplier and a zeroed addend
                 const bool piv = pre && lane == s;
+                double mi = piv ? ainv : -zi * inv;
+                if (piv) {
 #pragma unroll
-                for (int j = 0; j < MT; ++j) if (j != s) pp[j] = fma(mi, u[j], pp[j]);
-                pp[s] = pre ? zi * ainv : zi;
-                if (piv) {                                               // the pivot row itself
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) if (j != s) pp[j] = u[j] * ainv;
-                    pp[s] = -inv;
+                    for (int j = 0; j < MT; ++j) if (j != s) pp[j] = 0.0;
                 }
+                asm volatile("s_nop 1" : "+v"(mi));                      // a DPP read of a VALU result needs two wait states the assembler cannot see
+#pragma unroll
+                for (int j = 0; j < MT; ++j) if (j != s) lz_fmac_bcast(pp[j], zi, mi, j);
+                pp[s] = pre ? (piv ? -inv : zi * ainv) : zi;
             }
             if (lane < m) {                                              // the pivot rows' final entries wait in LDS until the flags are known
 #pragma unroll
@@ -264,6 +283,7 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
             break;
         }
         skip |= veto & (0u - veto);                                      // the first refused step changes every later one: one at a time
+        ++nveto;
         __syncthreads();
     }
     LZ_PSTAMP(13);
@@ -302,7 +322,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     long long best_pat = -1;
     double second_obj = __builtin_inf();
     long long second_pat = -1;
-    unsigned long long npiv = 0, nunconv = 0;
+    unsigned long long npiv = 0, nunconv = 0, nveto = 0;
 
 #ifdef PARTLS_LZ_STAMPS
     unsigned long long lz_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lz_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_last = __builtin_readcyclecounter();
@@ -460,8 +480,8 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     double *Zn = Zp + (size_t)Rcur * ld, *dn = dp + Rcur;
                     int acc_piv;
                     if constexpr (NT <= 512) {
-                        acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, LZ_STK)
-                                         : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, LZ_STK);
+                        acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK)
+                                         : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK);
                     } else {                                                  // 128 VGPRs per thread: the step-by-step form (two barriers per pivot, few registers)
                         acc_piv = gj_panel_eliminate<NT>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, p.piv_eps, tid);
                     }
@@ -523,6 +543,8 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
         __syncthreads();
     }
 #ifdef PARTLS_LZ_STAMPS
+    if (tid == NT - 64 && blockIdx.x == 0)
+        printf("lazy stamps, last wave: panel setup %llu p1 %llu p2 %llu bar %llu tail %llu\n", lz_cyc[8], lz_cyc[9], lz_cyc[11], lz_cyc[12], lz_cyc[13]);
     if (tid == 0 && blockIdx.x == 0)
         printf("lazy stamps (cycles, count): start %llu %llu | scan %llu %llu | flush %llu %llu | materialise %llu %llu | panel %llu %llu | post %llu %llu | flush k-loops %llu other %llu | panel: setup %llu p1 %llu bar %llu p2 %llu bar %llu tail %llu end %llu | pivots %llu mb %d rows %d\n",
                lz_cyc[0], lz_cnt[0], lz_cyc[1], lz_cnt[1], lz_cyc[2], lz_cnt[2], lz_cyc[3], lz_cnt[3], lz_cyc[4], lz_cnt[4], lz_cyc[5], lz_cnt[5], lz_cyc[6], lz_cyc[7], lz_cyc[8], lz_cyc[9], lz_cyc[10], lz_cyc[11], lz_cyc[12], lz_cyc[13], lz_cyc[14], npiv, mb, rows);
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
         if (p.second_obj) { p.second_obj[blockIdx.x] = second_obj; p.second_pat[blockIdx.x] = second_pat; }
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
+        if (p.n_vetoes && nveto) atomicAdd(p.n_vetoes, nveto);           // entering pivots refused by the leave-one-out rule (512-thread plan)
     }
 }
 
