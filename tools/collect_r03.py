@@ -63,6 +63,27 @@ for k, v in g.items():
                         "executed_flops_per_dispatch": v["SQ_INSTS_VALU_MFMA_F64"] / n * 2048}
 json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -- python3 tools/gram_bench.py 1000000 512 16 3",
            "kernels": g}, open(os.path.join(S, "r03_c4_gram_pmc.json"), "w"), indent=1)
+# beyond n = 320: kernel time and measured traffic of the deferred-update kernel against the eager one (same run, same problem)
+ls, es = kernel_stats("l340_stats", "r03_d340_lazy_kernel_stats.csv"), kernel_stats("e340_stats", "r03_d340_eager_kernel_stats.csv")
+def _traffic(tag, match):
+    f_, w_ = counters(tag + "_fetch", match), counters(tag + "_write", match)
+    fk_ = sum(v.get("FETCH_SIZE", 0) for v in f_.values()); wk_ = sum(v.get("WRITE_SIZE", 0) for v in w_.values())
+    n_ = max([v.get("dispatches", 1) for v in f_.values()] or [1])
+    return {"fetch_size_kib": fk_, "write_size_kib": wk_, "dispatches": n_, "hbm_bytes_per_launch": (2 * fk_ + wk_) * 1024 / n_}
+def _avg_ms(rows, match):
+    for r in rows or []:
+        if match in r.get("Name", ""): return float(r["AverageNs"]) / 1e6
+    return None
+if ls or es:
+    lz, eg = _traffic("l340", "sweep_lazy"), _traffic("e340", "sweep_generic")
+    lz["avg_ms"], eg["avg_ms"] = _avg_ms(ls, "sweep_lazy"), _avg_ms(es, "sweep_generic")
+    sq = counters("l340_sq", "sweep_lazy")
+    json.dump({"command": "rocprofv3 ... -- python3 tools/generic_timing.py 20000 340 18  (D = 340, K = 18: 2^18 patterns, two launches per run; "
+                          "tools/profile_r03.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)",
+               "deferred_update_kernel": lz, "eager_kernel (PARTLS_EAGER_GENERIC=1)": eg, "sq_counters_deferred": sq},
+              open(os.path.join(S, "r03_d340_traffic.json"), "w"), indent=1)
+p_ = os.path.join(O, "large_n.txt")
+if os.path.exists(p_): open(os.path.join(S, "r03_large_n.txt"), "w").write(open(p_).read())
 for f in ("bench_c2.json", "bench_c3.json", "bench_c4.json", "bench_c5.json"):
     p = os.path.join(O, f)
     if os.path.exists(p): open(os.path.join(S, "r03_" + f), "w").write(open(p).read())

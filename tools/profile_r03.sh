@@ -17,6 +17,18 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $O/c4_pmc -- $G > $O/c4_pmc.log 2>&1 || exit 1
 # C5: the 2^24-pattern enumeration + the BnB search with warm-started node bounds (bnb_hard leg: 170k nodes)
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -- python3 bench.py --config C5 --steps 1 --warmup 0 --no-cpu-baseline > $O/c5_stats.log 2>&1 || exit 1
+# beyond n = 320 (D = 340, 2^18 patterns): the deferred-update kernel (sweep_lazy.hip) and, for the A/B, the eager one (PARTLS_EAGER_GENERIC)
+L="python3 tools/generic_timing.py 20000 340 18"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l340_stats -- $L > $O/l340_stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/l340_fetch -- $L > $O/l340_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/l340_write -- $L > $O/l340_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 --output-format csv -d $O/l340_sq -- $L > $O/l340_sq.log 2>&1 || exit 1
+export PARTLS_EAGER_GENERIC=1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/e340_stats -- $L > $O/e340_stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/e340_fetch -- $L > $O/e340_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/e340_write -- $L > $O/e340_write.log 2>&1 || exit 1
+unset PARTLS_EAGER_GENERIC
+for d in 340 400 500 600; do python3 tools/generic_timing.py 20000 $d $(( d <= 400 ? 16 : 12 )) 2>/dev/null; done > $O/large_n.txt
 # plain bench lines of every config (no profiler attached)
 python3 bench.py --config C2 --steps 50 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err || exit 1
 python3 bench.py --config C3 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
