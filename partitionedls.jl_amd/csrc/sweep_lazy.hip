@@ -3,38 +3,34 @@
 // Same algorithm, same decisions and same SweepParams as sweep_generic.hip (block principal pivoting on the symmetric
 // principal-pivot tableau, Opt.jl:87-90 per pattern; node mode for BnB / Alt), one workgroup per Gray-code chain.  What differs is
 // where the bytes go.  sweep_generic.hip applies every block of <= 16 pivots to the whole (n+1)^2 / 2 triangle at once: 2 x 0.47 MB
-// through the memory system per block at n = 341 for ~0.7 MFLOP of work — it is bound by that traffic (1.05 M solves/s at D = 340).
+// through the memory system per block at n = 341 for ~0.7 MFLOP of work — it is bound by that traffic and its latency (1.06 M solves/s at D = 340).
 // But a block only ever READS m columns of the tableau (its pivot columns) and the rhs column.  So here
 //   * the rhs column q (and the objective corner) lives in LDS and follows every block at once;
 //   * the rank-1 terms of a block (z_s = pivot column s as of its own step, 1/d_s) are appended to a PENDING list in LDS (R terms);
-//   * a pivot column k is MATERIALISED on demand:  T[i][k] = base[i][k] - sum_{pending t >= max(ts_i, ts_k)} z_t[i] z_t[k] / d_t ;
+//   * a pivot column k is MATERIALISED on demand:  T[i][k] = base[i][k] - sum_t z_t[i] z_t[k] / d_t over the pending terms (MFMA);
 //   * the rows / columns of the pivoted variables, which a block REPLACES (T_ik = T_ik / |d|, T_kk = -1/d) rather than updates, are
-//     written to the base image at once (2 m n entries), and ts_k = "terms up to here are already in row / column k of the base";
-//   * only when the list is full is the base image brought up to date: ONE pass with a rank-R update (v_mfma_f64_16x16x4 on 16 x 16
-//     tiles of the upper triangle, the ts masks folded into the operands) — once per ~R pivots instead of once per block.
-// Bytes per pivot drop by R / (pivots per block) (~6x at n = 341: R = 34, blocks of 5.7), and the pass itself runs on the matrix
-// pipe with 16 x fewer LDS operand reads than the FMA form.  DESIGN.md §4 "Beyond n = 320".
+//     written to the base image at once (2 m n entries), and what the pending terms hold at those indices is ZEROED: an entry of the
+//     base is always "as of the last replacement of its row or column", and the terms older than that contribute exact zeros;
+//   * only when the pool is full is the base image brought up to date: ONE pass with a rank-R update (v_mfma_f64_16x16x4 on 16 x 16
+//     tiles of the upper triangle) — once per ~40 pivots instead of once per block.
+// Base-image bytes per pivot drop ~5x (measured: profiles/r03_d340_traffic.json), and the pass itself runs on the matrix pipe with
+// 16 x fewer LDS operand reads than the FMA form.  The panel of a block is eliminated in two phases with three barriers per block
+// (lz_panel_eliminate).  D = 340: 1.06 -> 4.0-4.5 M solves/s.  DESIGN.md §4 "Beyond n = 320".
 #include "gj_panel.h"
-#include <cstdlib>
 
 namespace partls {
 
 static constexpr int LZ_MAXWORDS = 16;      // n <= 1024
 static constexpr int LZ_MAXR = 64;          // rows of the LDS pool at most
 #ifndef LZ_MIN_SPLIT
+#ifndef LZ_SPIN_SLEEP
+#define LZ_SPIN_SLEEP 1                     // s_sleep argument of the phase-2 waves' poll of the panel's progress word
+#endif
 #define LZ_MIN_SPLIT 6                      // a block is cut short to fill the pool when at least this many pivots still fit
 #endif
 
 typedef double lz_double4 __attribute__((ext_vector_type(4)));
 
-#ifndef LZ_ABL
-#define LZ_ABL 0     // ablations of the flush (timing only, wrong results): 1 no stores, 2 no loads, 3 no MFMAs
-#endif
-#ifdef PARTLS_LZ_NT
-#define LZ_LOAD(p) __builtin_nontemporal_load(p)
-#else
-#define LZ_LOAD(p) (*(p))
-#endif
 #ifdef PARTLS_LZ_STAMPS     // diagnostic build: cycles of thread 0 of workgroup 0 per phase, printed at the end
 #define LZ_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); lz_cyc[slot] += now_ - lz_last; lz_last = now_; ++lz_cnt[slot]; } while (0)
 #else
@@ -144,6 +140,12 @@ __device__ __forceinline__ double lz_readlane(double v, int l)            // l: 
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double lz_bperm(double v, int srclane)        // v of lane `srclane` (any lane -> any lane; no LDS memory)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(srclane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // acc += y[lane 16 (lane / 16) + g] * x   (gfx90a+; semantics and rate checked by tools/ubench/fmac_dpp.hip)
 __device__ __forceinline__ void lz_fmac_bcast(double &acc, double y, double x, int g)
 {
@@ -202,14 +204,23 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
         if (tid == 0) __hip_atomic_store(prog, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         if (p1wave) {                                                    // ---- phase 1 -------------------------------------------
-            double pp[MT];
+            // All 64 lanes work: lane 16 g + j holds the entries of pivot row k_j in the four panel columns 4 g .. 4 g + 3.  A step needs, in
+            // every lane, column s at its own pivot row (zi: the multiplier) and at the pivot rows of its four columns (u): two wave
+            // permutes (ds_bpermute, no LDS memory) bring column s from the DPP row that owns it into every row — once as it is, once
+            // rotated by 4 g, so that u_{4g+c} sits in lane c of row g and v_fmac_f64_dpp row_newbcast:c hands it to the whole row.
+            // ~45 instructions per step instead of ~150 with all 16 columns in one lane (the step is bound by ONE wave's issue rate).
+            const int g = lane >> 4, jl = lane & 15;
+            const int krow1 = ks[jl < m ? jl : 0];
+            double pp[4];
 #pragma unroll
-            for (int j = 0; j < MT; ++j) pp[j] = (j < m && lane < m) ? Pn[j * ld + krow] : 0.0;
+            for (int c = 0; c < 4; ++c) pp[c] = (4 * g + c < m && jl < m) ? Pn[(4 * g + c) * ld + krow1] : 0.0;
 #pragma unroll
-            for (int s = 0; s < MT; ++s) {
+            for (int s = 0; s < GJ_MB; ++s) {
                 if (s >= m) break;                                       // uniform
-                const double zi = pp[s];
-                if (lane < MT) tabU[s * GJ_MB + lane] = zi;              // column s at the pivot rows: phase 2 reads it as broadcasts
+                const int gs = s >> 2, cs = s & 3;                       // the DPP row and register that hold column s
+                const double zi = lz_bperm(pp[cs], 16 * gs + jl);        // column s at pivot row j
+                const double zr = lz_bperm(pp[cs], 16 * gs + ((jl + 4 * g) & 15));   // ... at pivot row j + 4 g: lane c of row g = u_{4g+c}
+                if (lane < GJ_MB) tabU[s * GJ_MB + lane] = zi;           // phase 2 reads it as broadcasts
                 const double d = lz_readlane(zi, s);
                 const bool bas = (basm >> s) & 1u, skp = (skip >> s) & 1u;
                 const bool pre = !skp && (bas || d > piv_eps);           // uniform
@@ -220,24 +231,23 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
                 // above it — no s_waitcnt needed, only the compiler must keep the order
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_store(prog, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (lane < m) Zn[s * ld + krow] = zi;
-                // row update  pp[j] = fma(-zi / d, u_j, pp[j])  with u_j = lane j's zi taken by DPP (v_fmac_f64_dpp row_newbcast: the pivot
-                // rows sit in lanes 0..15, one DPP row); the pivot row itself becomes u_j |1/d| = fma(u_j, |1/d|, 0): same instruction with
-                // its own multiplier and a zeroed addend
-                const bool piv = pre && lane == s;
+                if (lane < m) Zn[s * ld + krow1] = zi;
+                // row update  pp[c] = fma(u_{4g+c}, -zi / d, pp[c]); the pivot row itself becomes u |1/d| = fma(u, |1/d|, 0): the same
+                // instruction with its own multiplier and a zeroed addend
+                const bool piv = pre && jl == s;
                 double mi = piv ? ainv : -zi * inv;
-                if (piv) {
-#pragma unroll
-                    for (int j = 0; j < MT; ++j) if (j != s) pp[j] = 0.0;
-                }
-                asm volatile("s_nop 1" : "+v"(mi));                      // a DPP read of a VALU result needs two wait states the assembler cannot see
-#pragma unroll
-                for (int j = 0; j < MT; ++j) if (j != s) lz_fmac_bcast(pp[j], zi, mi, j);
-                pp[s] = pre ? (piv ? -inv : zi * ainv) : zi;
+                if (piv) { pp[0] = 0.0; pp[1] = 0.0; pp[2] = 0.0; pp[3] = 0.0; }
+                double zrr = zr;
+                asm volatile("s_nop 1" : "+v"(mi), "+v"(zrr));           // a DPP read of a fresh VALU result needs two wait states the assembler cannot see
+                lz_fmac_bcast(pp[0], zrr, mi, 0);
+                lz_fmac_bcast(pp[1], zrr, mi, 1);
+                lz_fmac_bcast(pp[2], zrr, mi, 2);
+                lz_fmac_bcast(pp[3], zrr, mi, 3);
+                if (pre && g == gs) pp[cs] = piv ? -inv : zi * ainv;     // column s itself (what the fmac left there is not used)
             }
-            if (lane < m) {                                              // the pivot rows' final entries wait in LDS until the flags are known
+            if (jl < m) {                                                // the pivot rows' final entries wait in LDS until the flags are known
 #pragma unroll
-                for (int j = 0; j < MT; ++j) tabF[lane * GJ_MB + j] = pp[j];
+                for (int c = 0; c < 4; ++c) tabF[jl * GJ_MB + 4 * g + c] = pp[c];
             }
         }
         LZ_PSTAMP(9);
@@ -249,16 +259,22 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
                 if (s >= m) break;                                       // uniform
                 if (!p1wave) {                                           // (uniform) wait for the table row of step s
                     int spins = 0;
-                    while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                    while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(LZ_SPIN_SLEEP);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
+                // the whole table row in ONE batch of LDS reads, ahead of this step's LDS stores (the compiler cannot move a load across a
+                // store that may alias it: read in program order behind them, every ds_read2 pays its own round trip — 5 per step)
                 const double inv = tabI[s];                              // 0: refused — the row does not move
+                const double ds_ = tabD[s];
+                double u[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) u[j] = tabU[s * GJ_MB + j];
                 const double zi = pv[s];
-                if (!((basm >> s) & 1u) && var_row && (zi * zi) * piv_eps >= tabD[s]) red[s] = 1.0;   // only counted when 1/d != 0
+                if (!((basm >> s) & 1u) && var_row && (zi * zi) * piv_eps >= ds_) red[s] = 1.0;   // only counted when 1/d != 0
                 Zn[s * ld + tid] = zi;
                 const double mi = -zi * inv;
 #pragma unroll
-                for (int j = 0; j < MT; ++j) if (j != s) pv[j] = fma(mi, tabU[s * GJ_MB + j], pv[j]);
+                for (int j = 0; j < MT; ++j) if (j != s) pv[j] = fma(mi, u[j], pv[j]);
                 pv[s] = (inv != 0.0) ? zi * fabs(inv) : zi;
             }
         }
@@ -317,6 +333,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     double *T = p.scratch + (size_t)blockIdx.x * (size_t)ld * (size_t)ld;
     const int nwords = (n + 63) >> 6;
     const bool has_row = tid < ld;
+    const uint64_t mymask = (tid < n && !p.node_code) ? p.mask[tid] : 0;   // group membership of this thread's variable (chain mode)
 
     double best_obj = __builtin_inf();
     long long best_pat = -1;
@@ -366,7 +383,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     const int v = tid;
                     const double q = qs[v];
                     const int cd = code ? (int)code[v] : 0;
-                    const int f = code ? (cd == 2 ? 0 : cd) : lz_sign_of_var(p.mask[v], pat);
+                    const int f = code ? (cd == 2 ? 0 : cd) : lz_sign_of_var(mymask, pat);
                     const double fq = (f > 0) ? q : ((f < 0) ? -q : 0.0);
                     if (cd == 2) bad = !s_basic[v] && !s_blocked[v] && (fabs(q) > p.tol);     // free: stationarity only
                     else if (s_basic[v]) bad = (f == 0) || (fq < -p.tol);
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int row = (t0 + u) * 16 + fk + 4 * r, rc = row < n ? row : n - 1;
-                                    base[u][r] = (fr < m) ? LZ_LOAD(&T[lz_tri(rc, kcol, ld)]) : 0.0;
+                                    base[u][r] = (fr < m) ? T[lz_tri(rc, kcol, ld)] : 0.0;
                                     acc[u][r] = 0.0;
                                 }
                             }
@@ -487,20 +504,39 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     }
                     LZ_STAMP(4);                                              // panel
                     // ---- after the panel: rhs column, replaced rows / columns, bookkeeping -----------------------------
-                    const unsigned accm = (unsigned)__ballot(lane < m && dn[lane < m ? lane : 0] != 0.0);
+                    // All LDS reads of this phase go out in one batch, with clamped indices instead of loops bounded by m: a load behind a
+                    // store that may alias it waits for its own round trip (~130 cycles each, m of them in a row).
+                    const double dmy = dn[lane < m ? lane : 0];
+                    const unsigned accm = (unsigned)__ballot(lane < m && dmy != 0.0);
+                    int kmy = ks[lane < m ? lane : 0];                       // lane j of every wave: pivot variable j and 1/d_j
+                    double dmy_ = dmy;
+                    // both are read with v_readlane inside `if (has_row)`: pin their computation HERE, where every lane is active — the
+                    // compiler may otherwise sink the loads into the branch, and a wave whose last rows end below lane 15 (ld % 64 < 16)
+                    // would read lanes that never executed them
+                    asm volatile("" : "+v"(kmy), "+v"(dmy_));
                     if (has_row) {
-                        if (myj >= 0) qs[tid] = Pn[(size_t)myj * ld + n];
-                        else {
-                            double a = qs[tid];
-                            for (int s = 0; s < m; ++s)
-                                if ((accm >> s) & 1u) a = fma(-Zn[(size_t)s * ld + tid] * dn[s], Zn[(size_t)s * ld + n], a);
-                            qs[tid] = a;
+                        double zs[GJ_MB], zn[GJ_MB], pj[GJ_MB];
+#pragma unroll
+                        for (int j = 0; j < GJ_MB; ++j) {
+                            const int jc = j < m ? j : m - 1;
+                            zs[j] = Zn[(size_t)jc * ld + tid]; zn[j] = Zn[(size_t)jc * ld + n]; pj[j] = Pn[(size_t)jc * ld + tid];
                         }
-                    }
-                    if (tid < n) {
-                        // entry (k_a, k_b), a < b, is taken from panel column a: every entry of the base has exactly one writer
-                        for (int j = 0; j < m; ++j)
-                            if (myj < 0 || j <= myj) T[lz_tri(tid, ks[j], ld)] = Pn[(size_t)j * ld + tid];
+                        const double qn = myj >= 0 ? Pn[(size_t)myj * ld + n] : 0.0;
+                        double a = qs[tid];
+#pragma unroll
+                        for (int j = 0; j < GJ_MB; ++j) {
+                            const double dj = lz_readlane(dmy_, j);          // 0 beyond m and for refused pivots
+                            if ((accm >> j) & 1u) a = fma(-zs[j] * dj, zn[j], a);
+                        }
+                        qs[tid] = myj >= 0 ? qn : a;
+                        if (tid < n) {
+                            // entry (k_a, k_b), a < b, is taken from panel column a: every entry of the base has exactly one writer
+#pragma unroll
+                            for (int j = 0; j < GJ_MB; ++j) {
+                                const int kj = __builtin_amdgcn_readlane(kmy, j);
+                                if (j < m && (myj < 0 || j <= myj)) T[lz_tri(tid, kj, ld)] = pj[j];
+                            }
+                        }
                     }
                     // the rows / columns of the pivoted variables now hold ALL terms up to this block: what the pending terms (this
                     // block's included) say about them must never be applied again — zero it where it is stored (the entries a
@@ -591,8 +627,7 @@ hipError_t launch_sweep_lazy(const SweepParams &p, int grid, hipStream_t s)
     int mb = 0, rows = 0;
     size_t shmem = 0;
     if (!lazy_plan(p.n + 1, &mb, &rows, &shmem)) return hipErrorInvalidValue;
-    static const bool force1024 = getenv("PARTLS_LZ_1024") != nullptr;   // experiment
-    return (p.n + 1 <= 512 && !force1024) ? launch_lazy_nt<512>(p, grid, mb, rows, shmem, s) : launch_lazy_nt<1024>(p, grid, mb, rows, shmem, s);
+    return p.n + 1 <= 512 ? launch_lazy_nt<512>(p, grid, mb, rows, shmem, s) : launch_lazy_nt<1024>(p, grid, mb, rows, shmem, s);
 }
 
 }  // namespace partls
