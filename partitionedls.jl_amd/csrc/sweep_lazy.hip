@@ -70,25 +70,26 @@ __device__ __forceinline__ void lz_flush(double *T, int ld_, int n_, const doubl
     const int NTl = (n + 15) >> 4;                                          // tile rows / columns
     const int ksteps = (Rcur + 3) >> 2;
     constexpr int NW = NT / 64;
+    constexpr int SW = NT <= 512 ? 4 : 2;                                   // tiles per strip (2 x 8 x SW VGPRs: the 1024-thread plan has 128 in all)
     int nitems = 0;
-    for (int I = 0; I < NTl; ++I) nitems += (NTl - I + 3) >> 2;
+    for (int I = 0; I < NTl; ++I) nitems += (NTl - I + SW - 1) / SW;
     for (int w = wave; w < nitems; w += NW) {
         int I = 0, rem = w;
-        for (;;) { const int c = (NTl - I + 3) >> 2; if (rem < c) break; rem -= c; ++I; }
-        const int J0 = I + 4 * rem;
+        for (;;) { const int c = (NTl - I + SW - 1) / SW; if (rem < c) break; rem -= c; ++I; }
+        const int J0 = I + SW * rem;
         // EDGE: the strip reaches beyond row / column n - 1 (last tile row / column): clamped loads and operand reads (out-of-range results
         // are computed on valid data and not stored).  Interior strips — most — run without any of that.
         auto strip = [&](auto edge_c) {
             constexpr bool EDGE = decltype(edge_c)::value;
             const int ra = I * 16 + fr, ra_c = (EDGE && ra >= n) ? n - 1 : ra;
-            int cb[4], cb_c[4], off[4];
+            int cb[SW], cb_c[SW], off[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { cb[q] = (J0 + q) * 16 + fr; cb_c[q] = (EDGE && cb[q] >= n) ? n - 1 : cb[q]; }
+            for (int q = 0; q < SW; ++q) { cb[q] = (J0 + q) * 16 + fr; cb_c[q] = (EDGE && cb[q] >= n) ? n - 1 : cb[q]; }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int row = I * 16 + fk + 4 * r; off[r] = ((EDGE && row >= n) ? n - 1 : row) * ld; }
-            lz_double4 old[4], acc[4];
+            lz_double4 old[SW], acc[SW];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < SW; ++q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { old[q][r] = T[off[r] + cb_c[q]]; acc[q][r] = 0.0; }
             }
@@ -98,34 +99,34 @@ __device__ __forceinline__ void lz_flush(double *T, int ld_, int n_, const doubl
             // operands of k-step ks: term t = 4 ks + fk; the reads of step ks + 1 are in flight under the MFMAs of step ks
             const double *zr = Zp + fk * ld;
             const double *dr = dp + fk;
-            double za = zr[ra_c], zb[4], di = dr[0];
+            double za = zr[ra_c], zb[SW], di = dr[0];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) zb[q] = zr[cb_c[q]];
+            for (int q = 0; q < SW; ++q) zb[q] = zr[cb_c[q]];
             for (int ks = 0; ks < ksteps; ++ks) {
                 const double a = -za * di;
-                double b[4];
+                double b[SW];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) b[q] = zb[q];
+                for (int q = 0; q < SW; ++q) b[q] = zb[q];
                 zr += 4 * ld; dr += 4;                                      // one step beyond the last: rows of the pool / qs — read, never used
                 za = zr[ra_c]; di = dr[0];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) zb[q] = zr[cb_c[q]];
+                for (int q = 0; q < SW; ++q) zb[q] = zr[cb_c[q]];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[q], acc[q], 0, 0, 0);
+                for (int q = 0; q < SW; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[q], acc[q], 0, 0, 0);
             }
 #ifdef PARTLS_LZ_STAMPS
             asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
             fl_k += __builtin_readcyclecounter() - fl_t0; fl_t0 = __builtin_readcyclecounter();
 #endif
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < SW; ++q) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (!EDGE || (cb[q] < n && I * 16 + fk + 4 * r < n)) T[off[r] + cb_c[q]] = old[q][r] + acc[q][r];
                 }
             }
         };
-        if (I * 16 + 16 <= n && (J0 + 4) * 16 <= n) strip(std::false_type{});
+        if (I * 16 + 16 <= n && (J0 + SW) * 16 <= n) strip(std::false_type{});
         else strip(std::true_type{});
     }
 #ifdef PARTLS_LZ_STAMPS
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     // P[j][i] = base[i][k_j] - sum_t z_t[i] (z_t[k_j] / d_t): a (rows x terms) x (terms x 16) product on the matrix pipe, 16
                     // rows per MFMA tile (A[i][k] = z_t[i], B[k][j] = Cj[t][j]); C/D map: column j = lane & 15, row = (lane >> 4) + 4 reg.
                     {
-                        constexpr int TPW = 3;                     // tiles per wave and turn: their base loads are all in flight together
+                        constexpr int TPW = NT <= 512 ? 3 : 1;     // tiles per wave and turn: their base loads are all in flight together
                         const int fr = lane & 15, fk = lane >> 4, wv = tid >> 6;
                         const int ksteps = (Rcur + 3) >> 2, NTl = (n + 15) >> 4;
                         const int kcol = ks[fr < m ? fr : 0];
@@ -514,28 +515,42 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     // compiler may otherwise sink the loads into the branch, and a wave whose last rows end below lane 15 (ld % 64 < 16)
                     // would read lanes that never executed them
                     asm volatile("" : "+v"(kmy), "+v"(dmy_));
-                    if (has_row) {
-                        double zs[GJ_MB], zn[GJ_MB], pj[GJ_MB];
-#pragma unroll
-                        for (int j = 0; j < GJ_MB; ++j) {
-                            const int jc = j < m ? j : m - 1;
-                            zs[j] = Zn[(size_t)jc * ld + tid]; zn[j] = Zn[(size_t)jc * ld + n]; pj[j] = Pn[(size_t)jc * ld + tid];
-                        }
-                        const double qn = myj >= 0 ? Pn[(size_t)myj * ld + n] : 0.0;
-                        double a = qs[tid];
-#pragma unroll
-                        for (int j = 0; j < GJ_MB; ++j) {
-                            const double dj = lz_readlane(dmy_, j);          // 0 beyond m and for refused pivots
-                            if ((accm >> j) & 1u) a = fma(-zs[j] * dj, zn[j], a);
-                        }
-                        qs[tid] = myj >= 0 ? qn : a;
-                        if (tid < n) {
-                            // entry (k_a, k_b), a < b, is taken from panel column a: every entry of the base has exactly one writer
-#pragma unroll
+                    if constexpr (NT <= 512) {
+                        if (has_row) {
+                            double zs[GJ_MB], zn[GJ_MB], pj[GJ_MB];
+    #pragma unroll
                             for (int j = 0; j < GJ_MB; ++j) {
-                                const int kj = __builtin_amdgcn_readlane(kmy, j);
-                                if (j < m && (myj < 0 || j <= myj)) T[lz_tri(tid, kj, ld)] = pj[j];
+                                const int jc = j < m ? j : m - 1;
+                                zs[j] = Zn[(size_t)jc * ld + tid]; zn[j] = Zn[(size_t)jc * ld + n]; pj[j] = Pn[(size_t)jc * ld + tid];
                             }
+                            const double qn = myj >= 0 ? Pn[(size_t)myj * ld + n] : 0.0;
+                            double a = qs[tid];
+    #pragma unroll
+                            for (int j = 0; j < GJ_MB; ++j) {
+                                const double dj = lz_readlane(dmy_, j);          // 0 beyond m and for refused pivots
+                                if ((accm >> j) & 1u) a = fma(-zs[j] * dj, zn[j], a);
+                            }
+                            qs[tid] = myj >= 0 ? qn : a;
+                            if (tid < n) {
+                                // entry (k_a, k_b), a < b, is taken from panel column a: every entry of the base has exactly one writer
+    #pragma unroll
+                                for (int j = 0; j < GJ_MB; ++j) {
+                                    const int kj = __builtin_amdgcn_readlane(kmy, j);
+                                    if (j < m && (myj < 0 || j <= myj)) T[lz_tri(tid, kj, ld)] = pj[j];
+                                }
+                            }
+                        }
+                    } else if (has_row) {                                     // 128 VGPRs per thread: no room for the batch (48 doubles)
+                        if (myj >= 0) qs[tid] = Pn[(size_t)myj * ld + n];
+                        else {
+                            double a = qs[tid];
+                            for (int s = 0; s < m; ++s)
+                                if ((accm >> s) & 1u) a = fma(-Zn[(size_t)s * ld + tid] * dn[s], Zn[(size_t)s * ld + n], a);
+                            qs[tid] = a;
+                        }
+                        if (tid < n) {
+                            for (int j = 0; j < m; ++j)
+                                if (myj < 0 || j <= myj) T[lz_tri(tid, ks[j], ld)] = Pn[(size_t)j * ld + tid];
                         }
                     }
                     // the rows / columns of the pivoted variables now hold ALL terms up to this block: what the pending terms (this

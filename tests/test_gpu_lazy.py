@@ -55,10 +55,11 @@ def _oracle_sample(oracle, X, y, P, pats):
     return oracle.opt_patterns(R, z, Po, np.asarray(pats))
 
 
-@pytest.mark.parametrize("D,K,chain_len", [(330, 7, None), (333, 8, None), (340, 10, 256), (352, 6, 16), (447, 6, None), (511, 5, None)])
+@pytest.mark.parametrize("D,K,chain_len", [(330, 7, None), (333, 8, None), (340, 10, 256), (352, 6, 16), (447, 6, None), (480, 5, None), (511, 5, None)])
 def test_every_pattern_equals_the_eager_kernel_and_the_oracle(partls, oracle, monkeypatch, D, K, chain_len):
     """512-thread plan (n = D + 1 <= 512).  D = 330: the last wave with tableau rows ends below lane 16 (ld = 332: 12 rows) — the
-    cross-lane reads of the kernel must not depend on lanes without a row.  chain_len 256 at K = 10: eight chains of 256 patterns, ~150 flushes each; 16: chain starts
+    cross-lane reads of the kernel must not depend on lanes without a row; D = 447 / 480: the wave that runs phase 1 of the panel also
+    owns 1 / 34 tableau rows; D = 511 (n = 512): the first size on the 1024-thread plan.  chain_len 256 at K = 10: eight chains of 256 patterns, ~150 flushes each; 16: chain starts
     dominate (the first pattern of a chain is solved from the empty basis: ~n/2 pivots in blocks of 16)."""
     X, y, P = _problem(1000 + D, 2 * D + 50, D, K)
     lz = _sweep(partls, monkeypatch, X, y, P, eager=False, chain_len=chain_len)
