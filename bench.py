@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — the hot path of PartitionedLS on MI355X, one BASELINE.json config per run (default C3, the headline).
 
-    python bench.py --gpus 1 --steps K --warmup W [--config C2|C3|C4|C5]
+    python bench.py --gpus 1 --steps K --warmup W [--config C2|C3|C4|C5|L340]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over the synthetic problem, inputs resident in HBM when the timed region starts.
@@ -35,6 +35,9 @@ CONFIGS = {
     "C3": ("opt", 20260003, 100_000, 256, 20),
     "C4": ("alt", 20260004, 1_000_000, 512, 16),
     "C5": ("bnb", 20260005, 100_000, 256, 24),
+    # not a BASELINE config: fit(Opt) beyond the register kernel (n = 340 > 320 tableau variables), the deferred-update kernel
+    # sweep_lazy.hip; same problem as tools/generic_timing.py 20000 340 18, whose rocprofv3 passes give the HBM traffic below
+    "L340": ("opt", 7, 20_000, 340, 18),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # public datasheet (vector = matrix fp64 on MI355X); not in the on-image guides
@@ -197,26 +200,48 @@ def main():
                 break
         # The binding bound of the sweep is fp64 FMA issue: the tableau lives in registers and is never re-read from HBM, so every
         # pivot costs one rank-1 update of the symmetric tableau = T(T+1)/2 tile slots x 256 FMAs, whatever the memory system does.
-        out["roofline"] = {"bound": "fp64-valu", "achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": fp64_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3, "pivots_per_launch": res["pivots"],
-                           "flop_per_pivot": (tiles * (tiles + 1) // 2) * 256 * 2, "solves_per_launch": solves_per_launch,
-                           "note": "algorithmic flops = principal pivots x tile slots x 256 x 2 (counted by the kernel) / HIP-event time of "
-                                   "the sweep launch; peak = 78.6 TFLOP/s fp64 vector (public datasheet; not in the on-image guide)"}
-        out["roofline_hbm"] = None if traffic is None else {
-            "bound": "hbm", "achieved": traffic / sweep_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": traffic / sweep_avg_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
-            "note": "MEASURED HBM bytes of the sweep launch (chain-start tableau loads and their scratch) / kernel time: HBM is idle"}
-        out["nominal_hbm"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                              "algorithmic_bytes_per_solve": bytes_per_solve,
-                              "note": "SURVEY §8(d) nominal bytes (G re-read per solve) x solves / kernel time. NOT a roofline fraction: "
-                                      "warm-started Gray chains keep the tableau in registers, the kernel never moves these bytes, so "
-                                      "the figure can exceed 1"}
-        out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "bit_order_calibration": avg("t_calib"),
-                             "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
-        out["gram"] = {"tflops_useful": gram_flops / (avg("t_gram") * 1e-3) / 1e12, "frac_of_fp64_mfma_peak":
-                       gram_flops / (avg("t_gram") * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-        out["result"] = {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"], "loo_vetoes": res["vetoes"]}
+        if n_tab > 320:
+            # Beyond the register kernel the tableau lives in global memory (sweep_lazy.hip): the bound that binds is HBM.  Bytes per
+            # sweep launch from the round's rocprofv3 FETCH_SIZE / WRITE_SIZE passes of the same problem (tools/profile_r03.sh).
+            lz_traffic, lz_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r03_d340_traffic.json")
+            if world == 1 and args.config == "L340" and not args.faithful and os.path.exists(tpath):
+                lz_traffic = json.load(open(tpath))["deferred_update_kernel"].get("hbm_bytes_per_sweep")
+                lz_src = "offline PMC (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel on this problem), profiles/r03_d340_traffic.json — not measured in this run"
+            pass_flops = res["pivots"] * float(n_tab) * n_tab          # every pivot: one rank-1 update of the triangle, n^2/2 entries x 2 flop
+            out["roofline"] = {"bound": "hbm", "achieved": None if lz_traffic is None else lz_traffic / sweep_avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": None if lz_traffic is None else lz_traffic / sweep_avg_s / 1e9 / HBM_PEAK_GBS,
+                               "traffic": lz_traffic, "traffic_source": lz_src, "kernel": "sweep_lazy_kernel", "kernel_ms": sweep_avg_s * 1e3,
+                               "pivots_per_launch": res["pivots"], "solves_per_launch": solves_per_launch,
+                               "note": "MEASURED bytes (the kernel's own traffic: passes over the base image, gathered and replaced rows / "
+                                       "columns) / HIP-event time of the sweep launch; the eager kernel of round 2 moves 5x more"}
+            out["roofline_fp64"] = {"bound": "fp64-mfma", "achieved": pass_flops / sweep_avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": pass_flops / sweep_avg_s / 1e12 / FP64_PEAK_TFLOPS,
+                                    "note": "pivots x n^2 flop (the rank-R passes over the base image, v_mfma_f64_16x16x4) / sweep time"}
+            out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "bit_order_calibration": avg("t_calib"),
+                                 "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
+            out["result"] = {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"], "loo_vetoes": res["vetoes"]}
+        else:
+            out["roofline"] = {"bound": "fp64-valu", "achieved": fp64_tflops,   "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fp64_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
+                               "kernel": "sweep_blk_kernel", "kernel_ms": sweep_avg_s * 1e3, "pivots_per_launch": res["pivots"],
+                               "flop_per_pivot": (tiles * (tiles + 1) // 2) * 256 * 2, "solves_per_launch": solves_per_launch,
+                               "note": "algorithmic flops = principal pivots x tile slots x 256 x 2 (counted by the kernel) / HIP-event time of "
+                                       "the sweep launch; peak = 78.6 TFLOP/s fp64 vector (public datasheet; not in the on-image guide)"}
+            out["roofline_hbm"] = None if traffic is None else {
+                "bound": "hbm", "achieved": traffic / sweep_avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": traffic / sweep_avg_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": traffic,
+                "note": "MEASURED HBM bytes of the sweep launch (chain-start tableau loads and their scratch) / kernel time: HBM is idle"}
+            out["nominal_hbm"] = {"achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_solve": bytes_per_solve,
+                                  "note": "SURVEY §8(d) nominal bytes (G re-read per solve) x solves / kernel time. NOT a roofline fraction: "
+                                          "warm-started Gray chains keep the tableau in registers, the kernel never moves these bytes, so "
+                                          "the figure can exceed 1"}
+            out["kernels_ms"] = {"gram_build": avg("t_gram"), "prep": res["t_prep"], "bit_order_calibration": avg("t_calib"),
+                                 "sweep": sweep_avg_s * 1e3, "finish": res["t_finish"]}
+            out["gram"] = {"tflops_useful": gram_flops / (avg("t_gram") * 1e-3) / 1e12, "frac_of_fp64_mfma_peak":
+                           gram_flops / (avg("t_gram") * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+            out["result"] = {"opt": res["opt"], "best_index": res["best_index"], "unconverged": res["unconv"], "loo_vetoes": res["vetoes"]}
         if kind == "bnb":
             out["bnb"] = {"seconds": sum(h["bnb"]["seconds"] for h in hist) / len(hist), "nodes_bounded": res["bnb"]["nopen"],
                           "opt": res["bnb"]["opt"], "gap_vs_opt": abs(res["bnb"]["opt"] - res["opt"]) / res["opt"],

@@ -69,7 +69,9 @@ def _traffic(tag, match):
     f_, w_ = counters(tag + "_fetch", match), counters(tag + "_write", match)
     fk_ = sum(v.get("FETCH_SIZE", 0) for v in f_.values()); wk_ = sum(v.get("WRITE_SIZE", 0) for v in w_.values())
     n_ = max([v.get("dispatches", 1) for v in f_.values()] or [1])
-    return {"fetch_size_kib": fk_, "write_size_kib": wk_, "dispatches": n_, "hbm_bytes_per_launch": (2 * fk_ + wk_) * 1024 / n_}
+    # the script runs the sweep twice (plus the short calibration launch of the first prepare, ~1 ms): bytes per SWEEP = total / 2
+    return {"fetch_size_kib": fk_, "write_size_kib": wk_, "dispatches": n_, "hbm_bytes_per_launch": (2 * fk_ + wk_) * 1024 / n_,
+            "hbm_bytes_per_sweep": (2 * fk_ + wk_) * 1024 / 2}
 def _avg_ms(rows, match):
     for r in rows or []:
         if match in r.get("Name", ""): return float(r["AverageNs"]) / 1e6
@@ -84,7 +86,7 @@ if ls or es:
               open(os.path.join(S, "r03_d340_traffic.json"), "w"), indent=1)
 p_ = os.path.join(O, "large_n.txt")
 if os.path.exists(p_): open(os.path.join(S, "r03_large_n.txt"), "w").write(open(p_).read())
-for f in ("bench_c2.json", "bench_c3.json", "bench_c4.json", "bench_c5.json"):
+for f in ("bench_c2.json", "bench_c3.json", "bench_c4.json", "bench_c5.json", "bench_l340.json"):
     p = os.path.join(O, f)
     if os.path.exists(p): open(os.path.join(S, "r03_" + f), "w").write(open(p).read())
 print("summaries in", S, sorted(os.listdir(S)))

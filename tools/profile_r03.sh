@@ -34,4 +34,5 @@ python3 bench.py --config C2 --steps 50 --warmup 5 > $O/bench_c2.json 2> $O/benc
 python3 bench.py --config C3 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
 python3 bench.py --config C4 --steps 5 --warmup 1 > $O/bench_c4.json 2> $O/bench_c4.err || exit 1
 python3 bench.py --config C5 --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err || exit 1
+python3 bench.py --config L340 --steps 5 --warmup 1 > $O/bench_l340.json 2> $O/bench_l340.err || exit 1
 python3 tools/collect_r03.py $O
