@@ -667,7 +667,17 @@ static int concurrency_T()
     }
     return 1;
 }
+int sweep_reg_concurrency_query(int T);
 int sweep_reg_concurrency(int T)
+{
+    // the occupancy query costs tens of microseconds — as much as a tenth of a whole C2-sized fit: asked once per tile count
+    static int cached[blk::MAXT + 2] = {0};
+    if (T >= 0 && T <= blk::MAXT && cached[T] > 0) return cached[T];
+    const int v = sweep_reg_concurrency_query(T);
+    if (T >= 0 && T <= blk::MAXT) cached[T] = v;
+    return v;
+}
+int sweep_reg_concurrency_query(int T)
 {
     switch (T) {
 #ifdef PARTLS_ONLY_T
