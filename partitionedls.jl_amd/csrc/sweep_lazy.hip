@@ -115,7 +115,7 @@ __device__ __forceinline__ void lz_flush(double *T, int ld_, int n_, const doubl
                 for (int q = 0; q < SW; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[q], acc[q], 0, 0, 0);
             }
 #ifdef PARTLS_LZ_STAMPS
-            asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[1][0]), "v"(acc[2][0]), "v"(acc[3][0]));
+            asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[SW - 1][0]));
             fl_k += __builtin_readcyclecounter() - fl_t0; fl_t0 = __builtin_readcyclecounter();
 #endif
 #pragma unroll
