@@ -199,7 +199,7 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
     // rows (if any) when it is through.  Every wait is on the last wave only, which never waits: no cycle.
     constexpr int P1W = NT / 64 - 1;
     const bool p1wave = (tid >> 6) == P1W;
-    int *prog = reinterpret_cast<int *>(red + GJ_MB);                    // red: [GJ_MB] flags, then this word
+    int *prog = reinterpret_cast<int *>(red + GJ_MB);                    // red: [GJ_MB] flags, this word, a failure flag
     for (;;) {
         if (tid < GJ_MB) red[tid] = 0.0;
         if (tid == 0) __hip_atomic_store(prog, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -261,6 +261,9 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
                 if (!p1wave) {                                           // (uniform) wait for the table row of step s
                     int spins = 0;
                     while (__hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(LZ_SPIN_SLEEP);
+                    // the wave polled sits in the same workgroup and never waits itself, so the bound (seconds) is never reached; should it
+                    // be, the solve must not pass for converged: the flag ends up in n_unconverged (PARTLS_ERR_NOT_CONVERGED)
+                    if (spins >= (1 << 22)) red[GJ_MB + 1] = 1.0;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 // the whole table row in ONE batch of LDS reads, ahead of this step's LDS stores (the compiler cannot move a load across a
@@ -348,6 +351,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     for (int i = tid; i < (rows + 4) * ld; i += NT) pool[i] = 0.0;   // everything the flush may read is finite from the start
     for (int i = tid; i < rows + GJ_MB; i += NT) dp[i] = 0.0;
     for (int i = tid; i < ld; i += NT) rowj[i] = -1;
+    if (tid == 0) red[GJ_MB + 1] = 0.0;                            // set if a wait on the panel's progress word ever ran into its bound
 
     const int64_t total = p.g_end - p.g_begin;
     const int64_t nchains = (total + p.chain_len - 1) / p.chain_len;
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
         p.best_pat[blockIdx.x] = best_pat;
         if (p.second_obj) { p.second_obj[blockIdx.x] = second_obj; p.second_pat[blockIdx.x] = second_pat; }
         if (p.n_pivots && npiv) atomicAdd(p.n_pivots, npiv);
+        if (red[GJ_MB + 1] != 0.0) ++nunconv;
         if (p.n_unconverged && nunconv) atomicAdd(p.n_unconverged, nunconv);
         if (p.n_vetoes && nveto) atomicAdd(p.n_vetoes, nveto);           // entering pivots refused by the leave-one-out rule (512-thread plan)
     }
