@@ -680,6 +680,7 @@ try {
     if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
+    c->knobs.no_export = getenv("PARTLS_NO_EXPORT") != nullptr;
     c->knobs.eager_generic = getenv("PARTLS_EAGER_GENERIC") != nullptr;
     c->knobs.bnb_cold = getenv("PARTLS_BNB_COLD") != nullptr;
     if (const char *e = getenv("PARTLS_BNB_BATCH")) c->knobs.bnb_batch = atoi(e);
@@ -945,6 +946,14 @@ try {
     p.n_vetoes = c->bestObj.as<unsigned long long>() + 2;
     for (int k = 0; k < 40; ++k) p.rbit.gbit[k] = (uint8_t)k;
     if (!c->order_identity) for (int k = 0; k < c->kbits; ++k) p.rbit.gbit[c->order.gbit[k]] = (uint8_t)k;   // exact ties: first REFERENCE index
+    // the register kernels leave the solution of every workgroup's best pattern behind: partls_opt_finish starts from the winner's
+    // instead of solving that pattern again from the empty basis (C2: 89 us of a 0.58 ms fit)
+    c->export_wg = -1;
+    if (c->use_reg && sweep_reg_small(c->T) && !c->knobs.no_export) {       // the 256-thread kernel (small tableaus) only
+        PARTLS_HIP_CHECK(c->bestSol.ensure((size_t)grid * n * sizeof(double)));
+        p.best_sol = c->bestSol.as<double>();
+        p.node_ld = n;
+    }
 
     t_begin(c, PARTLS_T_SWEEP);
     PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
@@ -984,11 +993,13 @@ try {
     }
     double bobj = INFINITY;
     int64_t bpat = -1;
+    int best_wg = -1;
     for (int i = 0; i < grid; ++i) {                     // argmin with first-index tie-break (Opt.jl:96)
         if (bp[(size_t)i] < 0) continue;
         bp[(size_t)i] = reference_pattern(c, bp[(size_t)i]);
-        if (bpat < 0 || bo[(size_t)i] < bobj || (bo[(size_t)i] == bobj && bp[(size_t)i] < bpat)) { bobj = bo[(size_t)i]; bpat = bp[(size_t)i]; }
+        if (bpat < 0 || bo[(size_t)i] < bobj || (bo[(size_t)i] == bobj && bp[(size_t)i] < bpat)) { bobj = bo[(size_t)i]; bpat = bp[(size_t)i]; best_wg = i; }
     }
+    if (p.best_sol) c->export_wg = best_wg;                 // row of bestSol that holds the winner's solution (valid while near_for == winner)
     // Near ties.  The tracked objective^2 carries the Gram form's absolute error (~eps * y'y times the pivots of the chain), so two
     // patterns closer than that can come out in the wrong order relative to the reference, which computes every objective from the
     // data (Opt.jl:90).  Candidates within that error of the winner — each workgroup reports its minimum and its runner-up — are
@@ -1038,6 +1049,8 @@ try {
             const uint64_t v = (uint64_t)q & kmask & used;
             if (std::find(cands.begin(), cands.end(), v) == cands.end()) cands.push_back(v);
         }
+    const int export_wg = (pattern == c->near_for) ? c->export_wg : -1;   // the sweep's winner: its solution was left behind by the kernel
+    c->export_wg = -1;
     c->near_for = -1;
     c->near_pat.clear();
 
@@ -1049,9 +1062,31 @@ try {
     double obest = INFINITY, loo_best = 0.0;
     uint64_t pbest = cands[0];
     for (size_t ci = 0; ci < cands.size(); ++ci) {
-        opt_codes(c, cands[ci], codes);
-        partls_status st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
-        if (st != PARTLS_OK) return st;
+        partls_status st = PARTLS_OK;
+        bool taken = false;
+        if (ci == 0 && export_wg >= 0) {
+            // the winner's solution as the sweep left it (scaled, 0 for nonbasic variables — the format of a node solve); accepted when
+            // it carries the winning pattern's signs (on an exact objective tie the kernel keeps the FIRST pattern's solution, which
+            // may belong to the other pattern of the tie), refined and KKT-checked below like any other
+            sols.assign((size_t)c->n, 0.0);
+            PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->bestSol.as<double>() + (size_t)export_wg * c->n, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            opt_codes(c, cands[ci], codes);
+            taken = true;
+            double smax = 0.0;
+            for (int i = 0; i < c->n; ++i) smax = std::max(smax, std::fabs(sols[(size_t)i]));
+            for (int i = 0; i < c->n && taken; ++i) {
+                const double v = sols[(size_t)i];
+                if (!std::isfinite(v)) taken = false;
+                else if (v != 0.0 && (codes[(size_t)i] == 0 || (codes[(size_t)i] == 1 && v < -1e-9 * smax) || (codes[(size_t)i] == -1 && v > 1e-9 * smax))) taken = false;
+            }
+            if (taken) { c->tab_valid = false; unconv = 0; }
+        }
+        if (!taken) {
+            opt_codes(c, cands[ci], codes);
+            st = solve_nodes(c, codes, 1, sols, obj2, &unconv, false, /*want_tab=*/true);
+            if (st != PARTLS_OK) return st;
+        }
         unscale_solution(c, sols.data(), w);
         RefineOut ro;
         st = refine_solution(c, w, !c->faithful, 2, &ro); // QR-level accuracy of the winner on ill-conditioned data

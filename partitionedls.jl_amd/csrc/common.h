@@ -40,6 +40,8 @@ struct SweepParams {
     double *all_opt;             // optional [2^kbits] objective per pattern index
     double *best_obj;            // [gridDim.x] per-workgroup minimum objective
     int64_t *best_pat;           // [gridDim.x] its pattern index (internal bit order; ties broken on the REFERENCE index, see rbit)
+    double *best_sol;            // optional [gridDim.x][node_ld] (register kernels, chain mode): scaled solution of the workgroup's best pattern
+                                 // (0 for nonbasic variables), written whenever the workgroup finds a new minimum
     double *second_obj;          // optional [gridDim.x]: the workgroup's runner-up (second smallest objective, a different pattern) and
     int64_t *second_pat;         // its pattern, -1 if none: candidates of the host's near-tie re-rank by the data objective (api.hip)
     BitOrder rbit;               // chain mode: rbit.gbit[b] = the reference's bit (group) that internal pattern bit b carries.  Only
@@ -106,6 +108,7 @@ hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 320)
 bool       sweep_reg_supported(int n);
 int        sweep_reg_tiles(int n);
+bool       sweep_reg_small(int T);                       // T tile columns run on the 256-thread kernel (which also exports best_sol)
 size_t     sweep_reg_t0_doubles(int T);                  // size of the tile-cyclic initial tableau
 int        sweep_reg_concurrency(int T);                 // chains a CU runs at the same time (1: the 512-thread kernel, > 1: small tableaus)
 hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, hipStream_t s);

@@ -53,6 +53,7 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    bool no_export = false;      // PARTLS_NO_EXPORT: the winner is always solved again from the empty basis (A/B tests)
     bool eager_generic = false;  // PARTLS_EAGER_GENERIC: n > 320 on sweep_generic.hip (every block applied to the whole tableau) instead of sweep_lazy.hip (A/B tests)
     int bnb_batch = 1024;        // PARTLS_BNB_BATCH: nodes bounded per device batch of the BnB search
     int bnb_pool_mb = 16384;     // PARTLS_BNB_POOL_MB: cap of the tableau-snapshot pool of the BnB search (warm-started node bounds)
@@ -92,7 +93,7 @@ struct partls_ctx {
     const int *permP = nullptr;
     // gram
     int ldg = 0, chunks = 0;
-    partls::DevBuf slab, G, maskAugD /* + maskTabP, permP: one upload */, scale, Tfull, T0reg, scratch, bestObj, bestPat, counters, allOpt,
+    partls::DevBuf slab, G, maskAugD /* + maskTabP, permP: one upload */, scale, Tfull, T0reg, scratch, bestObj, bestSol /* [workgroups][n]: solution of every workgroup's best pattern (register kernels) */, bestPat, counters, allOpt,
         wdev, partial, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic, altA, altGA, altHg,
         nodePiv, maskInt, allOptRef, bnbIn, bnbOut;
     // BnB: tableau snapshots of open nodes (solvers.hip: SnapshotPool), kept across fits; host staging of a node batch
@@ -126,6 +127,7 @@ struct partls_ctx {
     // winner's): partls_opt_finish re-ranks them by the objective computed from the data before it fixes the winner
     std::vector<int64_t> near_pat;
     int64_t near_for = -1;
+    int export_wg = -1;                            // row of bestSol with the solution of the last sweep's winner (-1: none)
     double last_kkt = 0.0;                         // data-space KKT violation of the last finished winner
     double last_min_loo = 0.0;                     // smallest leave-one-out pivot of the basis of the last refined node solve (0: unknown)
     unsigned long long sweep_vetoes = 0;           // leave-one-out refusals of the last sweep (node solves overwrite last_vetoes)

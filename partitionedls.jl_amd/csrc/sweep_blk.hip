@@ -303,6 +303,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
 
     double S[L::CNT];
     double q = 0.0, corner = 0.0;
+    double mybest = __builtin_inf();                      // chain mode: objective^2 of the pattern whose solution sits in p.best_sol
     const bool has_var = tid < n;
     bool basic = false, blocked = false;
     const int mypos = (tid & 15) * RS + (tid >> 4);       // panel row position of variable `tid` (tid < 16 T)
@@ -540,6 +541,18 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 }
             }
             if (p.all_opt && tid == THREADS - 1) p.all_opt[pat] = sqrt(obj2);
+            if constexpr (!NODE && W == 1) {
+                // (256-thread kernel only: in the 512-thread kernel the two extra live registers move 8 spills and cost 1.8 % of the C3 sweep,
+                // against 0.15 ms of a 50 ms fit saved)
+                // the workgroup's best pattern so far leaves its solution behind (rhs column of the basic variables, as node mode's
+                // node_sol): the host takes the winner's from here instead of solving that pattern again from the empty basis.  Every
+                // thread decides for itself on the replicated corner; on exact objective ties the FIRST pattern's solution stays (the
+                // host checks the solution against the winning pattern's signs and re-solves if they disagree).
+                if (p.best_sol && obj2 < mybest) {
+                    mybest = obj2;
+                    if (has_var) p.best_sol[(size_t)blockIdx.x * p.node_ld + tid] = basic ? q : 0.0;
+                }
+            }
             if (tid == THREADS - 1) {                                // lexicographic (objective, pattern) minimum: argmin's first-index rule
                 const double bo = s_best[0];
                 const long long bp = reinterpret_cast<long long *>(s_best)[1];
@@ -634,6 +647,7 @@ __global__ void layout_reg_kernel(const double *__restrict__ Tfull, int n, int T
 
 bool sweep_reg_supported(int n) { return n >= 1 && n <= 16 * blk::MAXT; }
 int sweep_reg_tiles(int n) { return (n + 15) / 16; }
+bool sweep_reg_small(int T) { return T <= blk::MAXT_S; }   // the 256-thread kernel (several chains per CU) runs this tile count
 size_t sweep_reg_t0_doubles(int T) { return (size_t)T * (T + 1) / 2 * 256 + 16 * (size_t)T + 8; }
 
 hipError_t launch_layout_reg(const double *Tfull, int n, int T, double *T0reg, hipStream_t s)

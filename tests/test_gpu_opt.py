@@ -347,3 +347,34 @@ def test_alt_feature_in_no_group_is_ignored_not_nan(partls, oracle):
     ref = oracle.fit_alt(X[:, :6], y, P[:6], np.delete(a0, 6), b0, T=50)
     assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
     np.testing.assert_allclose(m.α[:6], ref["alpha"], atol=1e-7)
+
+
+def test_winner_solution_left_by_the_sweep_equals_a_fresh_solve(partls, oracle, monkeypatch):
+    """Small tableaus (256-thread kernel): partls_opt_finish starts from the solution the sweep left for its winner instead of solving
+    that pattern again; PARTLS_NO_EXPORT=1 forces the re-solve.  Same winner, objective and model, in both intercept modes; a sharded
+    sweep (the winner may come from another shard: no export to use) agrees too."""
+    X, y, P, _ = _order_problem(seed=31, N=900, M=120, K=10)
+    ref = oracle.fit_opt(X, y, P)
+    res = {}
+    for mode in ("export", "resolve"):
+        if mode == "resolve":
+            monkeypatch.setenv("PARTLS_NO_EXPORT", "1")
+        else:
+            monkeypatch.delenv("PARTLS_NO_EXPORT", raising=False)
+        ctx = partls.Context(0)
+        for flags in (0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT):
+            ctx.opt_prepare(X, y, P, 0.0, flags)
+            bo, bp, _, unconv = ctx.opt_sweep(0, -1)
+            res[mode, flags] = ctx.opt_finish(bp)
+            assert unconv == 0
+        npat = ctx.num_patterns()
+        parts = [ctx.opt_sweep(*partls.dist.shard_range(npat, r, 2)) for r in range(2)]
+        res[mode, "sharded"] = ctx.opt_finish(min((p[0], p[1]) for p in parts)[1])
+        ctx.close()
+    for key in [k for k in res if k[0] == "export"]:
+        a, b, t, opt, bi = res[key]
+        a2, b2, t2, opt2, bi2 = res["resolve", key[1]]
+        assert bi == bi2 and abs(opt - opt2) <= 1e-12 * max(1.0, opt2) and abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+        np.testing.assert_allclose(a, a2, atol=1e-9)
+        np.testing.assert_allclose(b, b2, atol=1e-9)
+        assert abs(t - t2) <= 1e-9
