@@ -22,10 +22,10 @@ namespace partls {
 
 static constexpr int LZ_MAXWORDS = 16;      // n <= 1024
 static constexpr int LZ_MAXR = 64;          // rows of the LDS pool at most
-#ifndef LZ_MIN_SPLIT
 #ifndef LZ_SPIN_SLEEP
 #define LZ_SPIN_SLEEP 1                     // s_sleep argument of the phase-2 waves' poll of the panel's progress word
 #endif
+#ifndef LZ_MIN_SPLIT
 #define LZ_MIN_SPLIT 6                      // a block is cut short to fill the pool when at least this many pivots still fit
 #endif
 
