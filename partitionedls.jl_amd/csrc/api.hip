@@ -949,7 +949,8 @@ try {
     // the register kernels leave the solution of every workgroup's best pattern behind: partls_opt_finish starts from the winner's
     // instead of solving that pattern again from the empty basis (C2: 89 us of a 0.58 ms fit)
     c->export_wg = -1;
-    if (c->use_reg && sweep_reg_small(c->T) && !c->knobs.no_export) {       // the 256-thread kernel (small tableaus) only
+    // (the 256-thread register kernel for small tableaus and the deferred-update kernel beyond n = 320; not the 512-thread kernel)
+    if (((c->use_reg && sweep_reg_small(c->T)) || (!c->use_reg && !c->knobs.eager_generic)) && !c->knobs.no_export) {
         PARTLS_HIP_CHECK(c->bestSol.ensure((size_t)grid * n * sizeof(double)));
         p.best_sol = c->bestSol.as<double>();
         p.node_ld = n;
@@ -1081,6 +1082,7 @@ try {
                 else if (v != 0.0 && (codes[(size_t)i] == 0 || (codes[(size_t)i] == 1 && v < -1e-9 * smax) || (codes[(size_t)i] == -1 && v > 1e-9 * smax))) taken = false;
             }
             if (taken) { c->tab_valid = false; unconv = 0; }
+            if (c->knobs.finish_trace) fprintf(stderr, "[finish] the sweep's solution of its winner (workgroup %d): %s\n", export_wg, taken ? "taken" : "refused (signs), solving again");
         }
         if (!taken) {
             opt_codes(c, cands[ci], codes);

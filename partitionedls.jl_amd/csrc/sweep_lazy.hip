@@ -344,6 +344,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     double second_obj = __builtin_inf();
     long long second_pat = -1;
     unsigned long long npiv = 0, nunconv = 0, nveto = 0;
+    double wg_best2 = __builtin_inf();                            // objective^2 of the pattern whose solution sits in p.best_sol (the same in every thread)
 
 #ifdef PARTLS_LZ_STAMPS
     unsigned long long lz_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lz_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_last = __builtin_readcyclecounter();
@@ -584,6 +585,12 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                 second_obj = best_obj; second_pat = best_pat;
                 best_obj = obj; best_pat = (long long)pat;
             } else if (obj < second_obj) { second_obj = obj; second_pat = (long long)pat; }
+            // the workgroup's best pattern so far leaves its solution behind (as sweep_blk.hip's 256-thread kernel does): the host takes
+            // the winner's from here instead of solving that pattern again — at n > 320 a 1.2 ms solve on the many-workgroup kernel
+            if (p.best_sol && !code && obj2 < wg_best2) {
+                wg_best2 = obj2;
+                for (int i = tid; i < n; i += NT) p.best_sol[(size_t)blockIdx.x * p.node_ld + i] = s_basic[i] ? qs[i] : 0.0;
+            }
             if (p.node_piv && code && tid == 0) {
                 unsigned *o = p.node_piv + 3 * ((size_t)chain * p.chain_len + (size_t)(g - g0));
                 o[0] = (unsigned)npiv; o[1] = 0; o[2] = 0;
