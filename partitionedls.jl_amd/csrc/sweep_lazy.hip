@@ -25,6 +25,9 @@ static constexpr int LZ_MAXR = 64;          // rows of the LDS pool at most
 #ifndef LZ_SPIN_SLEEP
 #define LZ_SPIN_SLEEP 1                     // s_sleep argument of the phase-2 waves' poll of the panel's progress word
 #endif
+#ifndef LZ_TWO_PHASE_MAX_NT
+#define LZ_TWO_PHASE_MAX_NT 512            // workgroup sizes up to this run the two-phase panel (the 1024-thread plan has 128 VGPRs per thread)
+#endif
 #ifndef LZ_MIN_SPLIT
 #define LZ_MIN_SPLIT 6                      // a block is cut short to fill the pool when at least this many pivots still fit
 #endif
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     LZ_STAMP(3);                                              // gather + materialise
                     double *Zn = Zp + (size_t)Rcur * ld, *dn = dp + Rcur;
                     int acc_piv;
-                    if constexpr (NT <= 512) {
+                    if constexpr (NT <= LZ_TWO_PHASE_MAX_NT) {
                         acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK)
                                          : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK);
                     } else {                                                  // 128 VGPRs per thread: the step-by-step form (two barriers per pivot, few registers)
