@@ -26,7 +26,7 @@ static constexpr int LZ_MAXR = 64;          // rows of the LDS pool at most
 #define LZ_SPIN_SLEEP 1                     // s_sleep argument of the phase-2 waves' poll of the panel's progress word
 #endif
 #ifndef LZ_TWO_PHASE_MAX_NT
-#define LZ_TWO_PHASE_MAX_NT 512            // workgroup sizes up to this run the two-phase panel (the 1024-thread plan has 128 VGPRs per thread)
+#define LZ_TWO_PHASE_MAX_NT 1024           // workgroup sizes up to this run the two-phase panel (512: the 1024-thread plan keeps the step-by-step one)
 #endif
 #ifndef LZ_MIN_SPLIT
 #define LZ_MIN_SPLIT 6                      // a block is cut short to fill the pool when at least this many pivots still fit
@@ -505,9 +505,11 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     LZ_STAMP(3);                                              // gather + materialise
                     double *Zn = Zp + (size_t)Rcur * ld, *dn = dp + Rcur;
                     int acc_piv;
-                    if constexpr (NT <= LZ_TWO_PHASE_MAX_NT) {
+                    if constexpr (NT <= 512) {
                         acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK)
                                          : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK);
+                    } else if constexpr (NT <= LZ_TWO_PHASE_MAX_NT) {         // 128 VGPRs per thread: blocks of at most 8 pivots (lazy_plan), the narrow panel only
+                        acc_piv = lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK);
                     } else {                                                  // 128 VGPRs per thread: the step-by-step form (two barriers per pivot, few registers)
                         acc_piv = gj_panel_eliminate<NT>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, p.piv_eps, tid);
                     }
@@ -636,6 +638,7 @@ bool lazy_plan(int ld, int *mb_out, int *rows_out, size_t *shmem_out)
     if (rows > LZ_MAXR) rows = LZ_MAXR;
     int mb = rows / 3;
     if (mb > GJ_MB) mb = GJ_MB;
+    if (ld > 512 && LZ_TWO_PHASE_MAX_NT >= 1024 && mb > 8) mb = 8;          // the 1024-thread plan compiles the 8-column panel only
     if (mb < 2) mb = 2;
     *mb_out = mb; *rows_out = rows;
     *shmem_out = ((size_t)(rows + 4) * ld + ld + rows + GJ_MB + (size_t)(rows + 4) * GJ_MB + 2 * GJ_MB * GJ_MB + 2 * GJ_MB + 18) * 8 + 3 * (size_t)ld + 16;
