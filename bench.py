@@ -111,8 +111,9 @@ def main():
         bobj, bpat, _, unconv = ctx.opt_sweep(g0, g1)
         t_gram, t_prep, t_sweep, t_calib = ctx.timing(L.T_GRAM), ctx.timing(L.T_PREP), ctx.timing(L.T_SWEEP), ctx.timing(L.T_CALIB)
         pivots, vetoes = ctx.pivots(), ctx.vetoes()
-        # all-reduce(min residual), then min pattern index among the minimisers (first-index argmin, Opt.jl:96)
-        _, bpat = pls.dist.allreduce_argmin(bobj, bpat, device=red_dev, order_key=okey)
+        # all-reduce(min residual), then one all-gather of every shard's winner + near ties (64 B per rank): the first-index argmin of
+        # Opt.jl:96 and the candidate set a single context would re-rank on the data objective — every rank finishes the same model
+        _, bpat = pls.dist.reduce_winner(ctx, bobj, bpat, device=red_dev, order_key=okey)
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         return dict(npat=npat, local=g1 - g0, opt=opt, best_index=bi, unconv=unconv, t_gram=t_gram, t_prep=t_prep,
                     t_sweep=t_sweep, t_calib=t_calib, t_finish=ctx.timing(L.T_FINISH), pivots=pivots, vetoes=vetoes)

@@ -93,6 +93,21 @@ partls_ctx   *partls_multi_context(partls_multi *mc, int rank);          /* NULL
 partls_status partls_fit_opt_multi(partls_multi *mc, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
                                    const int64_t *P, int64_t K, int64_t ldP, double eta, uint32_t flags,
                                    double *alpha, double *beta, double *t, double *opt, int64_t *best_index, double *all_opt);
+/* ---- fit(BnB) on several GPUs of one node, inside the library  — BnB.jl:94-132: subtrees are independent given the incumbent --------
+ * Same handle, same row-sharded upload and Gram sum as partls_fit_opt_multi.  Every rank thread runs the same best-first frontier
+ * (partls_frontier_*): per round the batch * R most promising nodes are dealt — a node goes to the rank that holds its parent's tableau
+ * snapshot (warm start), the surplus and the cold nodes to the least loaded ranks —, every rank bounds its share on its own GPU, and ONE
+ * all-gather of (bound, branch, snapshot slot) per round — ncclAllGather over xGMI; host memory for a device list with duplicates —
+ * carries the incumbent, so that all ranks prune, branch and count snapshot references identically.  The incumbent's model is built on
+ * the first device (partls_bnb_leaf, data passes over every rank's row block).  Outputs as partls_fit_bnb; *nopen = nodes bounded by
+ * all ranks (not a parity quantity: the search order differs from the reference's depth-first recursion). */
+partls_status partls_fit_bnb_multi(partls_multi *mc, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
+                                   const int64_t *P, int64_t K, int64_t ldP, double eta,
+                                   double *alpha, double *beta, double *t, double *opt, int64_t *nopen);
+/* Robustness of the rank threads (both fits): every phase ends in a rendezvous at which the ranks agree to go on or to leave together; a
+ * rank that cannot keep the protocol, or does not reach a rendezvous within PARTLS_MULTI_TIMEOUT_S seconds (default 3600), fails the
+ * fit with PARTLS_ERR_STATE instead of hanging it; a failed RCCL enqueue aborts the communicators (ncclCommAbort) and the handle
+ * reduces through host memory from then on (partls_multi_uses_rccl turns 0). */
 /* per-rank HIP-event time (ms) of stage `which` in the last partls_fit_opt_multi */
 partls_status partls_multi_get_timing(const partls_multi *mc, int rank, int which, double *ms);
 
@@ -114,6 +129,18 @@ partls_status partls_opt_sweep(partls_ctx *ctx, int64_t g_begin, int64_t g_end,
                                double *best_obj, int64_t *best_pattern, double *all_opt, int64_t *n_unconverged);
 partls_status partls_opt_finish(partls_ctx *ctx, int64_t pattern,
                                 double *alpha, double *beta, double *t, double *opt, int64_t *best_index);
+/* Near ties across shards.  The sweep ranks patterns on the Gram-form objective (absolute error ~eps * y'y); partls_opt_finish re-ranks
+ * the winner and the (at most 3) patterns within that error of it by the objective computed from the DATA, first reference index on exact
+ * ties (Opt.jl:90,96).  A host that shards the enumeration (one context per GPU) must give every rank the candidate set a single
+ * context would have had:
+ *   candidates: the shard's winner and its near ties with their tracked objectives, best first (count <= 4 <= capacity);
+ *   merge:      the concatenation of ALL ranks' candidate lists (any order; the same list on every rank) -> the global lexicographic
+ *               minimum (objective, reference index) in *win_obj / *win_pattern, installed together with its near ties for the next
+ *               partls_opt_finish(ctx, *win_pattern, ...) on this context.  Every rank then returns the same model.
+ * partls_fit_opt_multi does this between its rank threads; partitionedls.jl_amd/dist.py with one all-gather of 64 bytes per rank. */
+partls_status partls_opt_candidates(const partls_ctx *ctx, int64_t capacity, double *obj, int64_t *pattern, int64_t *count);
+partls_status partls_opt_merge_candidates(partls_ctx *ctx, int64_t count, const double *obj, const int64_t *pattern,
+                                          double *win_obj, int64_t *win_pattern);
 /* raw NNLS solution of one pattern b (reference indexing, K+1 bits): raw_alpha[M+1] >= 0 as nonneg_lsq returns it at
  * Opt.jl:89, and its optval (Opt.jl:90).  Needs a prepared context. */
 partls_status partls_opt_pattern(partls_ctx *ctx, int64_t pattern, double *raw_alpha, double *optval);
@@ -230,6 +257,8 @@ partls_status partls_get_vetoes(const partls_ctx *ctx, int64_t *vetoes);
  * returns PARTLS_ERR_ILL_CONDITIONED (see there).  min_pivot (optional): the smallest leave-one-out pivot of that model's basis on the
  * unit-diagonal scale, a lower bound of 1 / cond(G_BB) (0 when unknown). */
 partls_status partls_get_kkt_violation(const partls_ctx *ctx, double *violation, double *min_pivot);
+/* distinct subproblems the last partls_opt_finish solved and compared on the data objective (1: the sweep recorded no near tie) */
+partls_status partls_get_near_ties(const partls_ctx *ctx, int64_t *evaluated);
 /* debugging / tests: copy the Gram products of the prepared problem to the host: G ((M+2) x (M+2), column-major,
  * variables ordered [features, intercept, y]), i.e. G, c = G[:, M+1], yy = G[M+1, M+1], after η has been applied. */
 partls_status partls_get_gram(const partls_ctx *ctx, double *G_aug);

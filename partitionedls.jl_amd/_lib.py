@@ -32,11 +32,15 @@ SYMBOLS = [
     ("partls_multi_context", C.c_void_p, [C.c_void_p, C.c_int]),
     ("partls_fit_opt_multi", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
                                        C.c_uint32, _dp, _dp, _dp, _dp, _ip, _dp]),
+    ("partls_fit_bnb_multi", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, _i64, _i64, C.c_double,
+                                       _dp, _dp, _dp, _dp, _ip]),
     ("partls_multi_get_timing", C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp]),
     ("partls_opt_prepare", C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_int, C.c_void_p, _i64, _i64,
                                      C.c_double, C.c_uint32]),
     ("partls_opt_sweep", C.c_int, [C.c_void_p, _i64, _i64, _dp, _ip, _dp, _ip]),
     ("partls_opt_finish", C.c_int, [C.c_void_p, _i64, _dp, _dp, _dp, _dp, _ip]),
+    ("partls_opt_candidates", C.c_int, [C.c_void_p, _i64, _dp, _ip, _ip]),
+    ("partls_opt_merge_candidates", C.c_int, [C.c_void_p, _i64, _dp, _ip, _dp, _ip]),
     ("partls_opt_pattern", C.c_int, [C.c_void_p, _i64, _dp, _dp]),
     ("partls_opt_num_patterns", _i64, [C.c_void_p]),
     ("partls_opt_bit_order", C.c_int, [C.c_void_p, _ip, _dp]),
@@ -69,6 +73,7 @@ SYMBOLS = [
     ("partls_get_pivots", C.c_int, [C.c_void_p, _ip]),
     ("partls_get_vetoes", C.c_int, [C.c_void_p, _ip]),
     ("partls_get_kkt_violation", C.c_int, [C.c_void_p, _dp, _dp]),
+    ("partls_get_near_ties", C.c_int, [C.c_void_p, _ip]),
 ]
 
 _lib = None

@@ -6,6 +6,7 @@ fit(Opt|Alt|BnB, X, y, P; η, ...) / predict keep the reference's names, argumen
 """
 import atexit
 import ctypes as C
+import warnings
 import weakref
 from dataclasses import dataclass
 
@@ -61,9 +62,15 @@ def build_library(force=False):
     return L.build(force)
 
 
-def _check(st):
-    if st != L.OK:
+def _check(st, tolerate=()):
+    """Raise on a non-zero status, except one the caller handles itself (it gets the status back)."""
+    if st != L.OK and st not in tolerate:
         raise PartlsError(st, L.lib().partls_last_error().decode())
+    return st
+
+
+class IllConditionedWarning(UserWarning):
+    """The returned model failed the data-space KKT check (PARTLS_ERR_ILL_CONDITIONED): the fp64 Gram form cannot resolve this X."""
 
 
 def _dp(a):
@@ -82,7 +89,14 @@ class Context:
         _check(L.lib().partls_create(int(device), C.byref(self._h)))
         self.device = device
         self.generation = 0          # bumped by every prepare: lazily rebuilt results check it (see _Solutions)
+        self.tolerate_ill = False    # True: status 9 (outputs hold the best Gram-form model) is recorded in last_ill instead of raised
+        self.last_ill = False
         _live_contexts.add(self)
+
+    def _ill(self, st):
+        """status of a call whose outputs are filled even when it reports PARTLS_ERR_ILL_CONDITIONED (include/partls.h)"""
+        _check(st, (L.ERR_ILL_CONDITIONED,) if getattr(self, "tolerate_ill", False) else ())
+        self.last_ill = st == L.ERR_ILL_CONDITIONED
 
     def close(self):
         """Release the device objects now.  Also run for every live context by an atexit hook, i.e. BEFORE interpreter
@@ -146,8 +160,27 @@ class Context:
         t = C.c_double()
         o = C.c_double()
         bi = C.c_int64()
-        _check(L.lib().partls_opt_finish(self._h, int(pattern), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(bi)))
+        self._ill(L.lib().partls_opt_finish(self._h, int(pattern), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(bi)))
         return a, b, t.value, o.value, bi.value
+
+    def opt_candidates(self):
+        """(obj, pattern) arrays: this context's winner of the last sweep and its near ties (tracked objectives), best first."""
+        o = np.zeros(4); p = np.zeros(4, dtype=np.int64); n = C.c_int64()
+        _check(L.lib().partls_opt_candidates(self._h, 4, _dp(o), _ip(p), C.byref(n)))
+        return o[:n.value].copy(), p[:n.value].copy()
+
+    def opt_merge_candidates(self, objs, pats):
+        """Install the merged candidate lists of ALL ranks (same list on every rank): returns the global (objective, pattern) winner;
+        the next opt_finish(pattern) re-ranks it against its near ties on the data objective, as a single context would."""
+        o = np.ascontiguousarray(objs, dtype=np.float64); p = np.ascontiguousarray(pats, dtype=np.int64)
+        wo = C.c_double(); wp = C.c_int64()
+        _check(L.lib().partls_opt_merge_candidates(self._h, len(o), _dp(o), _ip(p), C.byref(wo), C.byref(wp)))
+        return wo.value, wp.value
+
+    def near_ties_evaluated(self):
+        n = C.c_int64()
+        _check(L.lib().partls_get_near_ties(self._h, C.byref(n)))
+        return n.value
 
     def opt_pattern(self, pattern):
         N, M, K = self._shape
@@ -162,15 +195,15 @@ class Context:
         a0 = np.ascontiguousarray(alpha0, dtype=np.float64); b0 = np.ascontiguousarray(beta0, dtype=np.float64)
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double(); it = C.c_int64()
-        _check(L.lib().partls_alt_prepared(self._h, float(eps), int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t),
-                                           C.byref(o), C.byref(it)))
+        self._ill(L.lib().partls_alt_prepared(self._h, float(eps), int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t),
+                                              C.byref(o), C.byref(it)))
         return a, b, t.value, o.value, it.value
 
     def bnb_prepared(self):
         N, M, K = self._shape
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double(); no = C.c_int64()
-        _check(L.lib().partls_bnb_prepared(self._h, _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
+        self._ill(L.lib().partls_bnb_prepared(self._h, _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
         return a, b, t.value, o.value, no.value
 
     def bnb_bound(self, pats, frees):
@@ -218,7 +251,7 @@ class Context:
         N, M, K = self._shape
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double()
-        _check(L.lib().partls_bnb_leaf(self._h, C.c_uint64(int(pat)), C.c_uint64(int(free)), _dp(a), _dp(b), C.byref(t), C.byref(o)))
+        self._ill(L.lib().partls_bnb_leaf(self._h, C.c_uint64(int(pat)), C.c_uint64(int(free)), _dp(a), _dp(b), C.byref(t), C.byref(o)))
         return a, b, t.value, o.value
 
     def timing(self, which):
@@ -325,10 +358,18 @@ class MultiContext:
         _check(L.lib().partls_multi_create(arr, n, C.byref(self._h)))
         self.generation = 0          # bumped by every fit (see _Solutions)
         self.devices = [int(d) for d in devices] if arr is not None else list(range(self.size))
+        self.tolerate_ill = False
+        self.last_ill = False
+        self._views = weakref.WeakSet()
         _live_contexts.add(self)
 
     def close(self):
         if self._h:
+            # the rank contexts die with the handle: views of them must not keep the raw pointers (a _Solutions object built on one
+            # notices the generation change and prepares its problem again on a context of its own)
+            self.generation += 1
+            for v in list(self._views):
+                v._h = C.c_void_p()
             L.lib().partls_multi_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -353,6 +394,8 @@ class MultiContext:
             raise IndexError("rank out of range")
         view = Context.__new__(Context)
         view._h, view.device, view.generation, view._borrowed, view._owner = C.c_void_p(h), None, 0, True, self
+        view.tolerate_ill, view.last_ill = self.tolerate_ill, False
+        self._views.add(view)
         return view
 
     def fit_opt(self, X, y, P, eta=0.0, flags=0, want_all=False):
@@ -365,11 +408,30 @@ class MultiContext:
         t = C.c_double(); o = C.c_double(); bi = C.c_int64()
         allopt = np.full(1 << (K + 1), np.nan) if want_all else None
         self.generation += 1
-        _check(L.lib().partls_fit_opt_multi(self._h, X.ctypes.data, N, M, N, y.ctypes.data, P.ctypes.data, K, M, float(eta),
-                                            int(flags), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(bi),
-                                            _dp(allopt) if want_all else None))
+        st = _check(L.lib().partls_fit_opt_multi(self._h, X.ctypes.data, N, M, N, y.ctypes.data, P.ctypes.data, K, M, float(eta),
+                                                 int(flags), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(bi),
+                                                 _dp(allopt) if want_all else None),
+                    (L.ERR_ILL_CONDITIONED,) if self.tolerate_ill else ())
+        self.last_ill = st == L.ERR_ILL_CONDITIONED
         self._shape = (N, M, K)
         return a, b, t.value, o.value, bi.value, allopt
+
+    def fit_bnb(self, X, y, P, eta=0.0):
+        """fit(BnB) with the frontier search sharded over the ranks (include/partls.h: partls_fit_bnb_multi): (alpha, beta, t, opt, nopen)"""
+        X = np.asfortranarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        P = np.asfortranarray(P, dtype=np.int64)
+        N, M = X.shape
+        K = P.shape[1]
+        a = np.zeros(M); b = np.zeros(K)
+        t = C.c_double(); o = C.c_double(); no = C.c_int64()
+        self.generation += 1
+        st = _check(L.lib().partls_fit_bnb_multi(self._h, X.ctypes.data, N, M, N, y.ctypes.data, P.ctypes.data, K, M, float(eta),
+                                                 _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)),
+                    (L.ERR_ILL_CONDITIONED,) if self.tolerate_ill else ())
+        self.last_ill = st == L.ERR_ILL_CONDITIONED
+        self._shape = (N, M, K)
+        return a, b, t.value, o.value, no.value
 
     def timing(self, rank, which):
         ms = C.c_double()
@@ -487,14 +549,19 @@ class _Solutions:
 
 
 def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="nnls", returnAllSolutions=False, rng=None,
-        alpha0=None, beta0=None, device=0, devices=None, faithful_intercept=False, generic_kernel=False):
+        alpha0=None, beta0=None, device=0, devices=None, faithful_intercept=False, generic_kernel=False, on_ill_conditioned="warn"):
     """fit(::Type{Opt|Alt|BnB}, X, y, P; η, ...) -> (PartLSFitResult, None, Report)   [Opt.jl:73, Alt.jl:50, BnB.jl:30]
 
     η/eta: regularisation (default 0.0);  Alt: ϵ/eps (1e-6), T (100), rng (None | int seed | numpy Generator) or an
     explicit starting point alpha0[M+1], beta0[K+1];  Opt: returnAllSolutions.
     faithful_intercept=True enumerates the reference's 2^(K+1) patterns instead of 2^K with a free intercept
-    (same optimum).  Opt, devices=... (None | count | list of device indices): the enumeration is sharded over those GPUs
-    inside the library (partls_fit_opt_multi: RCCL min-reduce), as the Julia drop-in does on a multi-GPU node.  nnlsalg is accepted for signature parity; the device solver is an exact active-set method.
+    (same optimum).  Opt / BnB, devices=... (None | count | list of device indices): the enumeration / the frontier search is sharded
+    over those GPUs inside the library (partls_fit_opt_multi: RCCL min-reduce; partls_fit_bnb_multi: one all-gather per round), as the
+    Julia drop-in does on a multi-GPU node.  nnlsalg is accepted for signature parity; the device solver is an exact active-set method.
+    on_ill_conditioned: what to do when the returned model fails the data-space KKT check (status 9: X beyond the fp64 Gram form;
+    the reference's QR-based NNLS still returns a model there, and the Julia patch reroutes to it): "warn" (default) returns the best
+    Gram-form model with report.ill_conditioned = True and report.kkt_violation set, and emits IllConditionedWarning; "raise" raises
+    PartlsError(status 9).
     """
     if alg not in (Opt, Alt, BnB):
         raise TypeError("fit: first argument must be Opt, Alt or BnB")
@@ -502,24 +569,40 @@ def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="n
     eps_v = 1e-6 if (ϵ is None and eps is None) else float(ϵ if ϵ is not None else eps)
     if nnlsalg not in ("nnls", "pivot", "fnnls"):
         raise ValueError("nnlsalg must be one of :nnls, :pivot, :fnnls")
+    if on_ill_conditioned not in ("warn", "raise"):
+        raise ValueError('on_ill_conditioned must be "warn" or "raise"')
     Xf, yf, Pf = _marshal(X, y, P)
     N, M = Xf.shape
     K = Pf.shape[1]
     ctx = default_context(device)
+    ctx.tolerate_ill = on_ill_conditioned == "warn"
+    ctx.last_ill = False
     lib = L.lib()
     Pout = np.array(Pf, dtype=np.int64, order="C")
+
+    def report(owner, **kw):
+        """the NamedTuple of the reference + what the data-space check said"""
+        if owner.last_ill:
+            kkt = ctx.kkt_violation() if owner is ctx else float("nan")
+            warnings.warn("partitionedls: the model's KKT conditions do not hold in data space (X is too ill-conditioned for the fp64 "
+                          "Gram form); the returned model is the best Gram-form one — " + L.lib().partls_last_error().decode(),
+                          IllConditionedWarning, stacklevel=3)
+            kw.update(ill_conditioned=True, kkt_violation=kkt)
+        return Report(**kw)
+
     if alg is Opt:
         flags = (L.OPT_FAITHFUL_INTERCEPT if (faithful_intercept or returnAllSolutions) else 0) | \
                 (L.OPT_GENERIC_KERNEL if generic_kernel else 0)
         if devices is not None:
             mc = default_multi(devices)
+            mc.tolerate_ill = ctx.tolerate_ill
             a, b, t, opt, bi, allopt = mc.fit_opt(Xf, yf, Pf, eta_v, flags, want_all=returnAllSolutions)
             model = PartLSFitResult(a, b, t, Pout)
             if returnAllSolutions:
                 c0 = mc.context(0)
                 c0._shape = (N, M, K)
-                return model, None, Report(solutions=_Solutions(c0, allopt, Pout, (Xf, yf, Pf, eta_v, flags, mc.devices[0])))
-            return model, None, Report(opt=opt, best_index=bi)
+                return model, None, report(mc, solutions=_Solutions(c0, allopt, Pout, (Xf, yf, Pf, eta_v, flags, mc.devices[0])))
+            return model, None, report(mc, opt=opt, best_index=bi)
         ctx.opt_prepare(Xf, yf, Pf, eta_v, flags)
         bobj, bpat, allopt, unconv = ctx.opt_sweep(0, -1, want_all=returnAllSolutions)
         if unconv:
@@ -527,8 +610,8 @@ def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="n
         a, b, t, opt, bi = ctx.opt_finish(bpat)
         model = PartLSFitResult(a, b, t, Pout)
         if returnAllSolutions:
-            return model, None, Report(solutions=_Solutions(ctx, allopt, Pout, (Xf, yf, Pf, eta_v, flags, device)))
-        return model, None, Report(opt=opt, best_index=bi)
+            return model, None, report(ctx, solutions=_Solutions(ctx, allopt, Pout, (Xf, yf, Pf, eta_v, flags, device)))
+        return model, None, report(ctx, opt=opt, best_index=bi)
     if alg is Alt:
         if alpha0 is None or beta0 is None:
             if rng is None:
@@ -546,16 +629,21 @@ def fit(alg, X, y, P, *, η=None, eta=None, ϵ=None, eps=None, T=100, nnlsalg="n
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double(); it = C.c_int64()
         ctx.generation += 1
-        _check(lib.partls_fit_alt(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v, eps_v,
-                                  int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(it)))
-        return PartLSFitResult(a, b, t.value, Pout), None, Report(opt=o.value, iters=it.value)
+        ctx._ill(lib.partls_fit_alt(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v, eps_v,
+                                    int(T), _dp(a0), _dp(b0), _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(it)))
+        return PartLSFitResult(a, b, t.value, Pout), None, report(ctx, opt=o.value, iters=it.value)
     if alg is BnB:
+        if devices is not None:
+            mc = default_multi(devices)
+            mc.tolerate_ill = ctx.tolerate_ill
+            a, b, t, opt, nopen = mc.fit_bnb(Xf, yf, Pf, eta_v)
+            return PartLSFitResult(a, b, t, Pout), None, report(mc, opt=opt, nopen=nopen)
         a = np.zeros(M); b = np.zeros(K)
         t = C.c_double(); o = C.c_double(); no = C.c_int64()
         ctx.generation += 1
-        _check(lib.partls_fit_bnb(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v,
-                                  _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
-        return PartLSFitResult(a, b, t.value, Pout), None, Report(opt=o.value, nopen=no.value)
+        ctx._ill(lib.partls_fit_bnb(ctx._h, Xf.ctypes.data, N, M, N, yf.ctypes.data, Pf.ctypes.data, K, M, eta_v,
+                                    _dp(a), _dp(b), C.byref(t), C.byref(o), C.byref(no)))
+        return PartLSFitResult(a, b, t.value, Pout), None, report(ctx, opt=o.value, nopen=no.value)
     raise TypeError("fit: first argument must be Opt, Alt or BnB")
 
 

@@ -80,7 +80,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     if (!(eta >= 0.0)) { set_error("eta must be >= 0"); return PARTLS_ERR_BAD_ARG; }
     c->prepared = false;
     c->peers.clear();                              // a row-sharded fit sets them again after every rank has prepared its block
-    c->near_for = -1; c->near_pat.clear();
+    c->near_for = -1; c->near_pat.clear(); c->cand.clear();
     c->sweep_vetoes = 0;
     c->coop_state_valid = false;
     c->order_ready = false; c->order_identity = true; c->flip_cost.clear(); c->ms[PARTLS_T_CALIB] = 0.0;
@@ -677,6 +677,7 @@ try {
     if (const char *e = getenv("PARTLS_COOP_ROWS")) c->knobs.coop_rows = atoi(e);
     if (const char *e = getenv("PARTLS_BIT_ORDER")) c->knobs.bit_order = !strcmp(e, "identity") ? 1 : (!strcmp(e, "calibrate") ? 2 : 0);
     if (const char *e = getenv("PARTLS_KKT_TOL")) c->knobs.kkt_tol = atof(e);
+    if (const char *e = getenv("PARTLS_NEAR_TIE_REL")) c->knobs.near_tie_rel = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WB")) c->knobs.cal_wb = atof(e);
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
@@ -1006,10 +1007,11 @@ try {
     // data (Opt.jl:90).  Candidates within that error of the winner — each workgroup reports its minimum and its runner-up — are
     // remembered (at most 3, best first); partls_opt_finish re-ranks them with the objective from the data.
     c->near_pat.clear();
+    c->cand.clear();
     c->near_for = bpat;
     if (bpat >= 0) {
         const double yy = h_reg(c, (int)c->M + 1, (int)c->M + 1);
-        const double lim2 = bobj * bobj + 1e-13 * (yy > 0.0 ? yy : 0.0);
+        const double lim2 = bobj * bobj + c->knobs.near_tie_rel * (yy > 0.0 ? yy : 0.0);
         std::vector<std::pair<double, int64_t>> cand;
         const double *so = sweep_out.data() + 4 + 2 * (size_t)grid;
         const int64_t *sp = reinterpret_cast<const int64_t *>(sweep_out.data() + 4 + 3 * (size_t)grid);
@@ -1018,7 +1020,9 @@ try {
             if (sp[i] >= 0 && so[i] * so[i] <= lim2) { const int64_t r = reference_pattern(c, sp[i]); if (r != bpat) cand.emplace_back(so[i], r); }
         }
         std::sort(cand.begin(), cand.end());
-        for (size_t i = 0; i < cand.size() && c->near_pat.size() < 3; ++i) c->near_pat.push_back(cand[i].second);
+        cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+        c->cand.emplace_back(bobj, bpat);
+        for (size_t i = 0; i < cand.size() && c->near_pat.size() < 3; ++i) { c->near_pat.push_back(cand[i].second); c->cand.push_back(cand[i]); }
     }
     if (best_obj) *best_obj = bobj;
     if (best_pattern) *best_pattern = bpat;
@@ -1054,6 +1058,7 @@ try {
     c->export_wg = -1;
     c->near_for = -1;
     c->near_pat.clear();
+    c->last_near_evaluated = (int64_t)cands.size();
 
     t_begin(c, PARTLS_T_FINISH);
     const auto f0 = std::chrono::steady_clock::now();
@@ -1334,6 +1339,56 @@ try {
     return PARTLS_OK;
 }
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+// ---- near ties across shards -------------------------------------------------------------------------------------------------------
+// A sharded enumeration (partls_fit_opt_multi's rank threads, dist.py's processes) must re-rank the SAME candidate set a single context
+// would (Opt.jl:90,96: every objective from the data, first index on ties): each shard hands out its winner and its near ties with
+// their tracked objectives, the lists of all shards are concatenated in rank order, and every rank installs the merged set.
+partls_status partls_opt_candidates(const partls_ctx *c, int64_t capacity, double *obj, int64_t *pattern, int64_t *count)
+try {
+    if (!c || !c->prepared || !count || capacity < 0 || (capacity > 0 && (!obj || !pattern))) { set_error("partls_opt_candidates: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    const int64_t n = std::min<int64_t>(capacity, (int64_t)c->cand.size());
+    for (int64_t i = 0; i < n; ++i) { obj[i] = c->cand[(size_t)i].first; pattern[i] = c->cand[(size_t)i].second; }
+    *count = n;
+    return PARTLS_OK;
+}
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_opt_merge_candidates(partls_ctx *c, int64_t count, const double *obj, const int64_t *pattern, double *win_obj, int64_t *win_pattern)
+try {
+    if (!c || !c->prepared || count < 0 || (count > 0 && (!obj || !pattern))) { set_error("partls_opt_merge_candidates: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    std::vector<std::pair<double, int64_t>> all;
+    for (int64_t i = 0; i < count; ++i) if (pattern[i] >= 0 && obj[i] == obj[i]) all.emplace_back(obj[i], pattern[i]);
+    std::sort(all.begin(), all.end());                        // lexicographic (objective, reference index): argmin's first-index rule
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    const int64_t local_winner = c->cand.empty() ? -1 : c->cand[0].second;
+    c->near_pat.clear();
+    c->cand.clear();
+    if (all.empty()) { c->near_for = -1; c->export_wg = -1; if (win_obj) *win_obj = INFINITY; if (win_pattern) *win_pattern = -1; return PARTLS_OK; }
+    const double bobj = all[0].first;
+    const int64_t bpat = all[0].second;
+    const double yy = h_reg(c, (int)c->M + 1, (int)c->M + 1);
+    const double lim2 = bobj * bobj + c->knobs.near_tie_rel * (yy > 0.0 ? yy : 0.0);
+    c->cand.push_back(all[0]);
+    for (size_t i = 1; i < all.size() && c->near_pat.size() < 3; ++i)
+        if (all[i].second != bpat && all[i].first * all[i].first <= lim2) { c->near_pat.push_back(all[i].second); c->cand.push_back(all[i]); }
+    c->near_for = bpat;
+    if (local_winner != bpat) c->export_wg = -1;             // the solution this rank's sweep left behind belongs to another pattern
+    if (win_obj) *win_obj = bobj;
+    if (win_pattern) *win_pattern = bpat;
+    return PARTLS_OK;
+}
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_get_near_ties(const partls_ctx *c, int64_t *evaluated)
+try {
+    if (!c || !evaluated) { set_error("partls_get_near_ties: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *evaluated = c->last_near_evaluated;
+    return PARTLS_OK;
+}
 catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_gram(const partls_ctx *c, double *G_aug)

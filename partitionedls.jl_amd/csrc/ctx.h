@@ -65,6 +65,7 @@ struct partls_knobs {
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
     double kkt_tol = 1e-12;      // PARTLS_KKT_TOL: data-space KKT violation of the winner (units of ||x_m|| ||y||) above which fit(Opt) / fit(BnB) report
                                  // PARTLS_ERR_ILL_CONDITIONED instead of PARTLS_OK (see kkt_says_ill_conditioned, api.hip)
+    double near_tie_rel = 1e-13; // PARTLS_NEAR_TIE_REL (tests): width of the near-tie window of the sweep, in units of y'y on the objective^2
     double cal_wb = 1.0, cal_ws = 1.0;  // PARTLS_CAL_WB / PARTLS_CAL_WS: multipliers of the block / scan weights of the bit-order cost model (experiments)
     int bit_order = 0;           // PARTLS_BIT_ORDER: 0 automatic (calibrate when the sweep is long enough to repay it), "identity" = 1
                                  // (group k on Gray bit k), "calibrate" = 2 (always measure; small problems in the tests)
@@ -127,6 +128,10 @@ struct partls_ctx {
     // winner's): partls_opt_finish re-ranks them by the objective computed from the data before it fixes the winner
     std::vector<int64_t> near_pat;
     int64_t near_for = -1;
+    // the same with the tracked objectives, winner first: what the ranks of a sharded enumeration exchange (partls_opt_candidates /
+    // partls_opt_merge_candidates) so that every rank re-ranks the set a single context would
+    std::vector<std::pair<double, int64_t>> cand;
+    int64_t last_near_evaluated = 0;               // distinct subproblems the last partls_opt_finish solved (1: no near tie)
     int export_wg = -1;                            // row of bestSol with the solution of the last sweep's winner (-1: none)
     double last_kkt = 0.0;                         // data-space KKT violation of the last finished winner
     double last_min_loo = 0.0;                     // smallest leave-one-out pivot of the basis of the last refined node solve (0: unknown)

@@ -12,6 +12,7 @@
 //     incumbent prunes (BnB.jl:102); the node count depends on the search order and is not a parity quantity.  A feature of
 //     several groups collects one constraint per branched group (BnB.jl:120-121): opposite ones force it to 0.
 #include "ctx.h"
+#include "frontier.h"
 #include <new>
 #include <chrono>
 #include <cstdio>
@@ -172,106 +173,6 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
 
 }  // namespace
 
-// ---- the frontier of the BnB search (host runtime, shared by the in-library search and the rank-sharded one of dist.py) ----------------
-// fit_BnB (BnB.jl:94-132) as a best-first search: the frontier is ordered by the parent's bound, a round pops the `batch * world` most
-// promising nodes (pruned against the incumbent, BnB.jl:102), DEALS them to the ranks, and — once every rank has bounded its share and
-// the (bound, branch, snapshot slot) triples have been exchanged — branches the survivors (BnB.jl:117-124).  Every rank runs the same
-// frontier on the same data, so it never has to be exchanged; only the triples are.  Dealing: a node whose parent left a tableau
-// snapshot goes to the rank that holds it (warm start) up to that rank's quota of the round; what exceeds the quota and every node
-// without a snapshot goes to the least loaded ranks and starts cold there (the tree spreads over the ranks by itself).  The frontier
-// also keeps the reference counts of the snapshots (two children per branched node) and tells each rank which of ITS slots died.
-struct partls_frontier {
-    struct Node { double key; uint64_t pat, free_; unsigned long long seq; int owner, slot; };
-    struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
-    std::priority_queue<Node, std::vector<Node>, Cmp> heap;
-    int rank = 0, world = 1;
-    int64_t batch = 1024, bounded = 0;
-    unsigned long long seq = 0;
-    double mu = INFINITY;
-    uint64_t best_pat = 0, best_free = 0;
-    std::vector<std::vector<int>> refs;              // [owner][slot]: children of that snapshot still in the frontier or in flight
-    std::vector<Node> round;                         // the nodes of the current round, in popping order
-    std::vector<int> assign;                         // rank of every node of the round
-    std::vector<char> warm;                          // it starts from its parent's snapshot there
-    std::vector<int> dead;                           // this rank's slots that lost their last reference
-
-    void unref(int owner, int slot)
-    {
-        if (owner < 0) return;
-        if (--refs[(size_t)owner][(size_t)slot] == 0 && owner == rank) dead.push_back(slot);
-    }
-    void setref(int owner, int slot, int v)
-    {
-        std::vector<int> &r = refs[(size_t)owner];
-        if ((size_t)slot >= r.size()) r.resize((size_t)slot + 1024, 0);
-        r[(size_t)slot] = v;
-    }
-    // pops and deals the next round; per_rank[world] = nodes of every rank; this rank's share into pat / free / src (capacity: batch)
-    int64_t next(int64_t *mine, uint64_t *pat, uint64_t *fre, int32_t *src, int32_t *per_rank)
-    {
-        round.clear();
-        while (!heap.empty() && (int64_t)round.size() < batch * world) {
-            const Node nd = heap.top();
-            heap.pop();
-            if (nd.key >= mu) { unref(nd.owner, nd.slot); continue; }        // its bound can only be >= the parent's
-            round.push_back(nd);
-        }
-        const int64_t cnt = (int64_t)round.size();
-        const int64_t quota = (cnt + world - 1) / world;
-        std::vector<int64_t> load((size_t)world, 0);
-        assign.assign((size_t)cnt, -1);
-        warm.assign((size_t)cnt, 0);
-        for (int64_t i = 0; i < cnt; ++i) {
-            const int o = round[(size_t)i].owner;
-            if (o >= 0 && load[(size_t)o] < quota) { assign[(size_t)i] = o; warm[(size_t)i] = 1; ++load[(size_t)o]; }
-        }
-        for (int64_t i = 0; i < cnt; ++i) {
-            if (assign[(size_t)i] >= 0) continue;
-            int r = 0;
-            for (int q = 1; q < world; ++q) if (load[(size_t)q] < load[(size_t)r]) r = q;
-            assign[(size_t)i] = r; ++load[(size_t)r];
-        }
-        int64_t m = 0;
-        for (int64_t i = 0; i < cnt; ++i)
-            if (assign[(size_t)i] == rank) {
-                pat[m] = round[(size_t)i].pat; fre[m] = round[(size_t)i].free_;
-                src[m] = warm[(size_t)i] ? round[(size_t)i].slot : -1;
-                ++m;
-            }
-        for (int q = 0; q < world; ++q) per_rank[q] = (int32_t)load[(size_t)q];
-        *mine = m;
-        return cnt;
-    }
-    // results of the round in RANK-MAJOR order (rank 0's nodes in the order next() gave them to rank 0, then rank 1's, ...)
-    void ingest(const double *lb, const int32_t *br, const int32_t *dst)
-    {
-        const int64_t cnt = (int64_t)round.size();
-        std::vector<int64_t> at((size_t)world, 0), base((size_t)world + 1, 0);
-        for (int64_t i = 0; i < cnt; ++i) ++base[(size_t)assign[(size_t)i] + 1];
-        for (int q = 0; q < world; ++q) base[(size_t)q + 1] += base[(size_t)q];
-        for (int64_t i = 0; i < cnt; ++i) {
-            const Node &nd = round[(size_t)i];
-            const int me = assign[(size_t)i];
-            const int64_t j = base[(size_t)me] + at[(size_t)me]++;
-            ++bounded;
-            unref(nd.owner, nd.slot);                                         // this child no longer needs its parent's tableau
-            const double l = lb[j];
-            const int k = br[j], d = dst[j];
-            if (l >= mu || k < 0) {
-                if (l < mu) { mu = l; best_pat = nd.pat; best_free = nd.free_; }   // feasible for the original problem (BnB.jl:109-115)
-                if (d >= 0 && me == rank) dead.push_back(d);
-                continue;
-            }
-            const uint64_t bit = 1ULL << k;
-            if (d >= 0) setref(me, d, 2);                                     // both children start from this node's tableau
-            const int o = d >= 0 ? me : -1, sl = d >= 0 ? d : -1;
-            heap.push({l, nd.pat | bit, nd.free_ & ~bit, seq++, o, sl});      // alpha_pk >= 0 first (BnB.jl:120,123)
-            heap.push({l, nd.pat & ~bit, nd.free_ & ~bit, seq++, o, sl});     // alpha_pk <= 0
-        }
-        round.clear();
-    }
-};
-
 extern "C" {
 
 partls_status partls_fit_alt(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y,
@@ -306,6 +207,10 @@ try {
     };
     auto w_from = [&]() { feature_mul(); for (int m = 0; m < Mp; ++m) w[(size_t)m] = a[(size_t)m] * f[(size_t)m]; };
     std::vector<int8_t> codes((size_t)c->n);
+    // what the data-space check after the loop needs of the LAST iteration: the alpha-step's raw solution w = f∘α (before checkalpha and
+    // the renormalisation), its constraint codes over [features, intercept], and the diagonal of the beta-step system
+    std::vector<double> wv, hdiag((size_t)Kp, 0.0);
+    std::vector<int8_t> vcode_last((size_t)Mp, 0);
 
     double oldopt = 1e20, optval = 1e10;                 // Alt.jl:73-74
     int64_t i = 1;
@@ -321,8 +226,8 @@ try {
         if (st != PARTLS_OK) return st;
         const unsigned long long apiv = c->last_pivots, ablk = c->last_blocks;
         unconv_total += unconv;
-        std::vector<double> wv;
         unscale_solution(c, sols.data(), wv);
+        for (int v = 0; v < c->n; ++v) vcode_last[(size_t)c->perm[(size_t)v]] = codes[(size_t)v];
         for (int m = 0; m < Mp; ++m) {
             const double am = (f[(size_t)m] != 0.0) ? wv[(size_t)m] / f[(size_t)m] : 0.0;
             a[(size_t)m] = am > 0.0 ? am : 0.0;
@@ -367,19 +272,50 @@ try {
             for (int k2 = 0; k2 < Kp; ++k2) hb += H0[(size_t)k * Kp + k2] * b[(size_t)k2];
             o2 += b[(size_t)k] * (hb - 2.0 * g0[(size_t)k]);
         }
+        for (int k = 0; k < Kp; ++k) hdiag[(size_t)k] = H0[(size_t)k * Kp + k];
         oldopt = optval;
         optval = std::sqrt(o2 > 0.0 ? o2 : 0.0);
         if (c->knobs.alt_trace) fprintf(stderr, "[alt] iter %d: alpha-step %.3f ms (%llu pivots, %llu blocks), rest %.3f ms\n", (int)i, std::chrono::duration<double, std::milli>(tt1 - tt0).count(), apiv, ablk, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt1).count());
         ++i;
     }
     w_from();
-    // Final objective.  The loss of the last iteration, beta'H beta - 2 g'beta + y'y from the K' x K' system, carries an absolute error
-    // of ~eps * y'y (cancellation against y'y): relative to opt^2 that is below 1e-10 as long as opt^2 > 1e-6 * y'y, and then it IS
-    // the result; only a near-interpolating fit (the reference's toy: opt = 0) pays the extra pass over X (0.87 ms of 4.1 GB at C4).
+    // Final objective and the data-space check of the last iteration (round 4).  Both solves of an iteration work on the Gram form — the
+    // alpha-step on the tableau, the beta-step on the K' x K' normal equations A'GA beta = A'c, whose condition is the SQUARE of that of the
+    // reference's QR solve (Alt.jl:110) — so the model is verified against the DATA before it is returned, as fit(Opt) / fit(BnB) verify
+    // theirs: one pass over X gives the loss (Alt.jl:112-113: no Gram cancellation) and g = Xo'(yo - Xo w) at the final w, and
+    //   * the beta-step is stationary iff A'g = 0: |sum_m A_mk g_m| in units of ||Xo A_k|| ||y|| per group;
+    //   * the alpha-step's KKT conditions (sign-constrained LS with the multipliers of the previous beta, Alt.jl:80-90) hold at ITS
+    //     solution w_alpha, which differs from the final w by the beta-step only: g_alpha = g + B (w - w_alpha) is carried over with the
+    //     host Gram copy (error ~eps |B| |w - w_alpha|: exact at convergence, ~1e-13 when the beta-step still moves w by O(1)) instead
+    //     of a second pass over X.
+    // Above PARTLS_KKT_TOL the call returns PARTLS_ERR_ILL_CONDITIONED with the model in the outputs (INTEGRATION.md reroutes that
+    // status to the stock Julia body).  Cost: two reads of X per fit (1.7 ms of 4.1 GB at C4).
     double dopt = optval;
-    if (!(optval * optval > 1e-6 * h_reg(c, Y, Y))) {
-        st = data_objective(c, w, &dopt);                // from the data: no Gram cancellation
-        if (st != PARTLS_OK) return st;
+    std::vector<double> g;
+    st = data_objective(c, w, &dopt, &g);
+    if (st != PARTLS_OK) return st;
+    c->last_kkt = 0.0;
+    c->last_min_loo = 0.0;
+    int worst = -1;
+    const char *which = "";
+    if (i > 1 && unconv_total == 0) {                        // at least one iteration ran
+        const double yy = h_reg(c, Y, Y), ynorm = std::sqrt(yy > 0.0 ? yy : 0.0);
+        for (int k = 0; k < Kp; ++k) {
+            double s = 0.0;
+            for (int m = 0; m < Mp; ++m) if ((c->mask_aug[(size_t)m] >> k) & 1ULL) s += a[(size_t)m] * g[(size_t)m];
+            const double nrm = std::sqrt(hdiag[(size_t)k] > 0.0 ? hdiag[(size_t)k] : 0.0) * (ynorm > 0.0 ? ynorm : 1.0);
+            const double v = nrm > 0.0 ? std::fabs(s) / nrm : 0.0;
+            if (v > c->last_kkt) { c->last_kkt = v; worst = k; which = "beta-step, group"; }
+        }
+        std::vector<double> ga(g);
+        for (int j = 0; j < Mp; ++j) {
+            const double dj = w[(size_t)j] - wv[(size_t)j];
+            if (dj == 0.0) continue;
+            for (int m = 0; m < Mp; ++m) ga[(size_t)m] += h_reg(c, m, j) * dj;
+        }
+        int wa = -1;
+        const double va = kkt_violation_data(c, wv, ga, vcode_last, &wa);
+        if (va > c->last_kkt) { c->last_kkt = va; worst = wa; which = "alpha-step, variable"; }
     }
     for (int64_t m = 0; m < M; ++m) alpha[m] = a[(size_t)m];
     for (int64_t k = 0; k < K; ++k) beta[k] = b[(size_t)k];
@@ -387,6 +323,11 @@ try {
     *opt = dopt;
     if (iters) *iters = i - 1;
     if (unconv_total) { set_error("partls_fit_alt: an alpha-step hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    if (kkt_says_ill_conditioned(c)) {
+        set_error("partls_fit_alt: the last iteration's solves do not hold in data space (violation %.2e of ||x|| ||y|| at %s %d, tolerance %.1e): "
+                  "X is too ill-conditioned for the fp64 Gram form; the outputs hold the Gram-form iterate", c->last_kkt, which, worst, c->knobs.kkt_tol);
+        return PARTLS_ERR_ILL_CONDITIONED;
+    }
     return PARTLS_OK;
 }
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
@@ -502,8 +443,13 @@ try {
     }
     unsigned long long unc = 0;
     partls_status st = bnb_bound_batch(c, (size_t)count, pat, free_, srcp.data(), dstp.data(), lb, branch, &unc);
-    if (st != PARTLS_OK) return st;
-    if (unc) { set_error("partls_bnb_bound_snap: a node bound hit the pivot cap"); return PARTLS_ERR_NOT_CONVERGED; }
+    if (st == PARTLS_OK && unc) { set_error("partls_bnb_bound_snap: a node bound hit the pivot cap"); st = PARTLS_ERR_NOT_CONVERGED; }
+    if (st != PARTLS_OK) {
+        // the host never learns these slots (it must not trust outputs of a failed call): back to the free list, or the pool would
+        // shrink by a batch with every failure until the next partls_bnb_snap_begin
+        for (int64_t i = 0; i < count; ++i) { if (dst_slot[i] >= 0) pool.drop(dst_slot[i]); dst_slot[i] = -1; }
+        return st;
+    }
     return PARTLS_OK;
 }
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }

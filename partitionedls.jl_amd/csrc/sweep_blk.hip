@@ -34,6 +34,7 @@
 // <= d_k, so d_k > piv_eps * T_jk^2 holds with a margin of 1e11 and every row can simply test its own entry; a leaving pivot
 // has 1/d < 0 and a rejected one 1/d = 0, which fail the test by sign.  Only the rhs row (no variable) must not report.
 #include "common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace partls {
@@ -685,10 +686,11 @@ int sweep_reg_concurrency_query(int T);
 int sweep_reg_concurrency(int T)
 {
     // the occupancy query costs tens of microseconds — as much as a tenth of a whole C2-sized fit: asked once per tile count
-    static int cached[blk::MAXT + 2] = {0};
-    if (T >= 0 && T <= blk::MAXT && cached[T] > 0) return cached[T];
+    // (atomic: the rank threads of partls_fit_opt_multi call this concurrently; every thread would store the same value)
+    static std::atomic<int> cached[blk::MAXT + 2];
+    if (T >= 0 && T <= blk::MAXT) { const int v = cached[T].load(std::memory_order_relaxed); if (v > 0) return v; }
     const int v = sweep_reg_concurrency_query(T);
-    if (T >= 0 && T <= blk::MAXT) cached[T] = v;
+    if (T >= 0 && T <= blk::MAXT) cached[T].store(v, std::memory_order_relaxed);
     return v;
 }
 int sweep_reg_concurrency_query(int T)

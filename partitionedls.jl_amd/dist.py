@@ -42,6 +42,42 @@ def allreduce_argmin(obj, pat, device=None, group=None, order_key=None):
     return gmin, (gpat if gpat != NO_CANDIDATE else -1)
 
 
+def reduce_winner(ctx, obj, pat, device=None, group=None, order_key=None):
+    """The sharded fit(Opt)'s reduction, near ties included: (objective, pattern) of the global lexicographic minimum, installed on
+    `ctx` together with the near ties of EVERY shard, so that the next ctx.opt_finish(pattern) re-ranks the candidate set a single
+    context would have had (Opt.jl:90,96: objectives from the data, first index on ties) and every rank returns the same model.
+
+    One all-reduce(min) on [objective, key, -key] — the min-residual reduction of the north star; the key of the visiting order is
+    checked inside it — and one all-gather of every rank's (at most 4) candidates: 64 bytes per rank, which also carries the index
+    (it replaces the masked index all-reduce of allreduce_argmin).  With one rank (or no process group) nothing is exchanged."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return obj, pat
+    world = dist.get_world_size(group)
+    key = 0.0 if order_key is None else float(order_key)
+    o = torch.tensor([obj if pat >= 0 else float("inf"), key, -key], dtype=torch.float64, device=device)
+    dist.all_reduce(o, op=dist.ReduceOp.MIN, group=group)
+    o = o.cpu()
+    if float(o[1]) != -float(o[2]):
+        raise RuntimeError("sharded Opt sweep: the ranks visit the patterns in different orders (Context.bit_order differs), "
+                           "so their Gray-index ranges do not partition the pattern space; prepare the same problem on every rank")
+    co, cp = ctx.opt_candidates() if pat >= 0 else (np.zeros(0), np.zeros(0, dtype=np.int64))
+    buf = torch.full((8,), float("inf"), dtype=torch.float64, device=device)       # [4 objectives | 4 patterns (exact in a double: < 2^41)]
+    buf[4:] = -1.0
+    if len(co):
+        buf[:len(co)] = torch.as_tensor(co)
+        buf[4:4 + len(cp)] = torch.as_tensor(cp.astype(np.float64))
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    g = torch.stack(out).cpu().numpy()
+    gobj, gpat = ctx.opt_merge_candidates(g[:, :4].ravel(), g[:, 4:].ravel().astype(np.int64))
+    if gpat >= 0 and gobj != float(o[0]):
+        raise RuntimeError("sharded Opt sweep: the all-reduced minimum and the gathered candidates disagree")
+    return gobj, gpat
+
+
 def bnb_search(bound_fn, n_groups, rank=0, world=1, group=None, batch=512, device=None, max_nodes=None):
     """fit_BnB (BnB.jl:94-132) as a best-first search whose frontier batches are sharded across ranks.
 

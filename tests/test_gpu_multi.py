@@ -175,3 +175,216 @@ def test_rows_sharded_over_the_ranks(partls, oracle, monkeypatch):
         assert bi == ref["best_index"]
     finally:
         mc.close()
+
+
+# ---- round 4: near ties across shards, fit(BnB) over the ranks, fault injection ---------------------------------------------------------
+def _intercept_near_tie_problem(seed, flip):
+    """strong group signal, intercept ~ 0: the two patterns that differ in the intercept's sign only are the top two of the faithful
+    enumeration (their objective^2 differ by ~ one unit of noise variance out of N) and sit in different halves of the Gray index"""
+    rng = np.random.default_rng(seed)
+    N, D, K = 400, 12, 3
+    X = rng.standard_normal((N, D)); X -= X.mean(axis=0)
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    w = rng.random(D) * np.array([2.0, -3.0, 1.5])[np.arange(D) % K]
+    y = X @ w + 0.5 * rng.standard_normal(N)
+    y = y - y.mean() + (0.02 if flip else -0.02)
+    return X, y, P
+
+
+@pytest.mark.parametrize("flip", [False, True])
+def test_near_tie_split_over_two_ranks_is_reranked_like_a_single_context(partls, monkeypatch, flip):
+    """The finish re-ranks the winner and its near ties on the objective computed from the data (Opt.jl:90,96).  With the pattern space
+    sharded, the runner-up may live on another rank: its candidates must reach the finish, so that partls_fit_opt_multi evaluates the
+    set a single context would and returns the same model.  The near-tie window (PARTLS_NEAR_TIE_REL, normally 1e-13 y'y) is widened
+    to sit between the gaps winner / second and winner / third of THIS problem: exactly one near tie exists, in the other shard."""
+    L = partls.lowlevel
+    X, y, P = _intercept_near_tie_problem(3, flip)
+    ctx = partls.Context(0)
+    ctx.opt_prepare(X, y, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
+    _, _, allopt, _ = ctx.opt_sweep(0, -1, want_all=True)
+    ctx.close()
+    order = np.argsort(allopt, kind="stable")
+    b1, b2, b3 = (int(v) for v in order[:3])
+    top = P.shape[1]                                                        # the intercept's bit: the top Gray bit of a short enumeration
+    assert (b1 ^ b2) == 1 << top, (b1, b2)                                  # winner and runner-up differ in the intercept's sign only
+    yy = float(y @ y)
+    g2, g3 = allopt[b2] ** 2 - allopt[b1] ** 2, allopt[b3] ** 2 - allopt[b1] ** 2
+    assert 0 < 2.5 * g2 < g3
+    monkeypatch.setenv("PARTLS_NEAR_TIE_REL", repr(float(1.6 * g2 / yy)))
+    ctx = partls.Context(0)
+    ctx.opt_prepare(X, y, P, 0.0, L.OPT_FAITHFUL_INTERCEPT)
+    bo, bp, _, _ = ctx.opt_sweep(0, -1)
+    co, cp = ctx.opt_candidates()
+    assert list(cp) == [b1, b2] and co[0] <= co[1]
+    a1, bt1, t1, opt1, bi1 = ctx.opt_finish(bp)
+    assert ctx.near_ties_evaluated() == 2
+    ctx.close()
+    mc = partls.MultiContext([0, 0])
+    try:
+        a, b, t, opt, bi, _ = mc.fit_opt(X, y, P, flags=L.OPT_FAITHFUL_INTERCEPT)
+        assert mc.context(0).near_ties_evaluated() == 2                      # the other shard's candidate reached rank 0's finish
+        assert bi == bi1 and abs(opt - opt1) <= 1e-12 * opt1                    # (the row-sharded Gram sum rounds differently)
+        np.testing.assert_allclose(a, a1, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(b, bt1, rtol=0, atol=1e-11)
+    finally:
+        mc.close()
+
+
+def test_candidates_merge_abi(partls, oracle):
+    """partls_opt_candidates / partls_opt_merge_candidates: what a process-per-GPU host (dist.reduce_winner) exchanges"""
+    X, y, P = _problem(oracle, N=800, D=20, K=5)
+    c0, c1 = partls.Context(0), partls.Context(0)
+    try:
+        for c in (c0, c1):
+            c.opt_prepare(X, y, P)
+        n = c0.num_patterns()
+        o0, p0, _, _ = c0.opt_sweep(0, n // 2)
+        o1, p1, _, _ = c1.opt_sweep(n // 2, n)
+        lists = [c0.opt_candidates(), c1.opt_candidates()]
+        assert lists[0][1][0] == p0 and lists[1][1][0] == p1
+        objs = np.concatenate([l[0] for l in lists]); pats = np.concatenate([l[1] for l in lists])
+        w0 = c0.opt_merge_candidates(objs, pats)
+        w1 = c1.opt_merge_candidates(objs[::-1].copy(), pats[::-1].copy())      # any order
+        assert w0 == w1 == min([(o0, p0), (o1, p1)])
+        r0 = c0.opt_finish(w0[1]); r1 = c1.opt_finish(w1[1])
+        assert abs(r0[3] - r1[3]) <= 1e-12 * r1[3] and r0[4] == r1[4]           # (one context starts from the solution its sweep left behind)
+        np.testing.assert_allclose(r0[0], r1[0], rtol=0, atol=1e-12)
+        ref = oracle.fit_opt(X, y, P)
+        assert r0[4] == ref["best_index"] and abs(r0[3] - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+        assert c0.opt_merge_candidates(np.zeros(0), np.zeros(0, dtype=np.int64)) == (float("inf"), -1)
+    finally:
+        c0.close(); c1.close()
+
+
+def _branching(seed=7, N=400, D=36, K=6):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    y = X @ rng.standard_normal(D) + 0.2 * rng.standard_normal(N)
+    return X, y, P
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_fit_bnb_multi_equals_the_single_context_search_and_the_oracle(partls, oracle, monkeypatch, devices):
+    """partls_fit_bnb_multi: one rank through the real RCCL communicator (ncclAllGather per round), 2 / 3 rank threads on device 0
+    through host memory — same optimum and model as partls_fit_bnb, as the oracle's depth-first recursion (BnB.jl:94-132) and as Opt.
+    Small batches, so that the search takes many rounds and the dealing (owner first, surplus cold) is exercised."""
+    monkeypatch.setenv("PARTLS_BNB_BATCH", "8")
+    X, y, P = _branching()
+    ref = oracle.fit_bnb(X, y, P)
+    c1 = partls.Context(0)                                                  # (a fresh context: the batch size is read at create)
+    c1.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    _, _, _, opt_single, nopen_single = c1.bnb_prepared()
+    c1.close()
+    mc = partls.MultiContext(devices)
+    try:
+        assert mc.uses_rccl == (len(devices) == 1)
+        a, b, t, opt, nopen = mc.fit_bnb(X, y, P)
+        assert nopen > 20
+        assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(opt - opt_single) <= 1e-12 * max(1.0, opt_single)
+        np.testing.assert_allclose(partls.predict(partls.PartLSFitResult(a, b, t, P), X),
+                                   oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"]), atol=1e-7)
+        if len(devices) == 1:
+            assert nopen == nopen_single                                     # one rank: the very same search
+        # eta > 0 and rows that do not divide by R; then the fit() front end
+        a, b, t, opt, nopen = mc.fit_bnb(X[:397], y[:397], P, eta=0.3)
+        refe = oracle.fit_bnb(X[:397], y[:397], P, eta=0.3)
+        assert abs(opt - refe["opt"]) <= 1e-9 * max(1.0, refe["opt"])
+    finally:
+        mc.close()
+    if len(devices) == 2:
+        m, _, rep = partls.fit(partls.BnB, X, y, P, devices=devices)
+        assert abs(rep.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and rep.nopen > 20
+
+
+def test_fit_bnb_multi_raw_ctypes_and_errors(partls):
+    lib = partls.lowlevel.lib()
+    L = partls.lowlevel
+    X, y, P = _branching(N=200, D=12, K=3)
+    Xf = np.asfortranarray(X); Pf = np.asfortranarray(P)
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.partls_multi_create(devs, 2, C.byref(h)) == L.OK
+    a = np.zeros(12); b = np.zeros(3); t = C.c_double(); o = C.c_double(); no = C.c_int64()
+    dp = lambda v: v.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.partls_fit_bnb_multi(h, Xf.ctypes.data, 200, 12, 200, y.ctypes.data, Pf.ctypes.data, 3, 12, 0.0, dp(a), dp(b), C.byref(t), C.byref(o),
+                                    C.byref(no)) == L.OK
+    assert no.value >= 1 and o.value > 0
+    assert lib.partls_fit_bnb_multi(None, Xf.ctypes.data, 200, 12, 200, y.ctypes.data, Pf.ctypes.data, 3, 12, 0.0, dp(a), dp(b), C.byref(t), C.byref(o),
+                                    C.byref(no)) == L.ERR_BAD_ARG
+    assert lib.partls_fit_bnb_multi(h, Xf.ctypes.data, 200, 12, 200, y.ctypes.data, Pf.ctypes.data, 3, 12, 0.0, None, dp(b), C.byref(t), C.byref(o),
+                                    C.byref(no)) == L.ERR_BAD_ARG
+    Pbad = Pf.copy(); Pbad[1, 1] = 3
+    assert lib.partls_fit_bnb_multi(h, Xf.ctypes.data, 200, 12, 200, y.ctypes.data, Pbad.ctypes.data, 3, 12, 0.0, dp(a), dp(b), C.byref(t), C.byref(o),
+                                    C.byref(no)) == L.ERR_BAD_PARTITION
+    assert lib.partls_fit_bnb_multi(h, Xf.ctypes.data, 200, 12, 200, y.ctypes.data, Pf.ctypes.data, 3, 12, 0.0, dp(a), dp(b), C.byref(t), C.byref(o),
+                                    C.byref(no)) == L.OK                   # the handle survives
+    lib.partls_multi_destroy(h)
+
+
+@pytest.mark.parametrize("alg", ["opt", "bnb"])
+@pytest.mark.parametrize("stage", [1, 2, 3, 4, 5])
+def test_a_rank_that_fails_at_any_stage_fails_the_fit_and_nobody_hangs(partls, oracle, monkeypatch, alg, stage):
+    """Fault injection (PARTLS_MULTI_FAULT=rank:stage): rank 1 of three (rank 0 for the finish) reports an error before the upload, inside
+    the Gram exchange, after its sweep / before the search, in the reduction / in the second search round, in the finish.  Every
+    other rank must leave its rendezvous; the fit returns that rank's status; the handle is usable afterwards."""
+    import time
+    monkeypatch.setenv("PARTLS_BNB_BATCH", "8")
+    monkeypatch.setenv("PARTLS_MULTI_FAULT", f"{0 if stage == 5 else 1}:{stage}")
+    monkeypatch.setenv("PARTLS_MULTI_TIMEOUT_S", "20")
+    X, y, P = _branching(N=300, D=18, K=4)
+    mc = partls.MultiContext([0, 0, 0])
+    monkeypatch.delenv("PARTLS_MULTI_FAULT")
+    try:
+        t0 = time.time()
+        with pytest.raises(partls.PartlsError) as ei:
+            mc.fit_opt(X, y, P) if alg == "opt" else mc.fit_bnb(X, y, P)
+        assert time.time() - t0 < 10.0                                        # by agreement, not by timeout
+        assert ei.value.status == partls.lowlevel.ERR_HIP and "injected fault" in str(ei.value), str(ei.value)
+        assert f"rank {0 if stage == 5 else 1}" in str(ei.value)
+    finally:
+        mc.close()
+    mc = partls.MultiContext([0, 0, 0])                                        # (no fault configured: the same sizes work)
+    try:
+        if alg == "opt":
+            assert abs(mc.fit_opt(X, y, P)[3] - oracle.fit_opt(X, y, P)["opt"]) <= 1e-9
+        else:
+            assert abs(mc.fit_bnb(X, y, P)[3] - oracle.fit_bnb(X, y, P)["opt"]) <= 1e-9
+    finally:
+        mc.close()
+
+
+@pytest.mark.parametrize("alg,stage", [("opt", 1), ("opt", 3), ("bnb", 3), ("bnb", 4)])   # (opt, 4: nothing is owed after the agreement in host mode)
+def test_a_rank_that_vanishes_is_caught_by_the_bounded_rendezvous(partls, monkeypatch, alg, stage):
+    """The rank thread simply returns (what a protocol bug would look like): the others wait PARTLS_MULTI_TIMEOUT_S at their rendezvous,
+    then the fit fails with PARTLS_ERR_STATE instead of hanging; a later fit on the same handle works (the barrier is reset)."""
+    import time
+    monkeypatch.setenv("PARTLS_BNB_BATCH", "8")
+    monkeypatch.setenv("PARTLS_MULTI_FAULT", f"1:{stage}:vanish")
+    monkeypatch.setenv("PARTLS_MULTI_TIMEOUT_S", "1.5")
+    X, y, P = _branching(N=300, D=18, K=4)
+    mc = partls.MultiContext([0, 0])
+    try:
+        t0 = time.time()
+        with pytest.raises(partls.PartlsError) as ei:
+            mc.fit_opt(X, y, P) if alg == "opt" else mc.fit_bnb(X, y, P)
+        assert 1.0 < time.time() - t0 < 15.0
+        assert ei.value.status == partls.lowlevel.ERR_STATE and "rendezvous" in str(ei.value), str(ei.value)
+    finally:
+        mc.close()
+
+
+def test_views_of_a_closed_multi_context_do_not_dangle(partls, oracle):
+    X, y, P = _problem(oracle, N=400, D=10, K=3)
+    mc = partls.MultiContext([0, 0])
+    m, _, rep = None, None, None
+    a, b, t, opt, bi, allopt = mc.fit_opt(X, y, P, want_all=True)
+    view = mc.context(0)
+    sols = partls.api._Solutions(view, allopt, P, (np.asfortranarray(X), y, np.asfortranarray(P), 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT, 0)) \
+        if hasattr(partls, "api") else None
+    mc.close()
+    assert not view._h                                                       # the borrowed handle is gone with its owner
+    if sols is not None:
+        view._shape = (X.shape[0], X.shape[1], P.shape[1])
+        o, model = sols[int(bi)]                                             # rebuilt on a private context, not through the dead view
+        assert abs(o - opt) <= 1e-9 * max(1.0, opt)
