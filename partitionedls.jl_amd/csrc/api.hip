@@ -686,6 +686,7 @@ try {
     c->knobs.bnb_cold = getenv("PARTLS_BNB_COLD") != nullptr;
     if (const char *e = getenv("PARTLS_BNB_BATCH")) c->knobs.bnb_batch = atoi(e);
     if (const char *e = getenv("PARTLS_BNB_POOL_MB")) c->knobs.bnb_pool_mb = atoi(e);
+    if (const char *e = getenv("PARTLS_BNB_WG_PER_CU")) c->knobs.bnb_wg_per_cu = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_FAULT")) c->knobs.coop_fault = atoi(e);
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
@@ -726,6 +727,7 @@ void partls_destroy(partls_ctx *c)
         for (void *q : c->bnbChunks) (void)hipFree(q);
         c->bnbChunks.clear();
         c->hG.release();
+        c->bnbHostIn.release(); c->bnbHostOut.release();
         if (c->hTab) (void)hipHostFree(c->hTab);
         if (c->hBasic) (void)hipHostFree(c->hBasic);
         for (int w = 0; w < PARTLS_T_COUNT; ++w) {

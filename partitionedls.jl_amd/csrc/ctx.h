@@ -24,15 +24,18 @@ struct DevBuf {
 // page-locked host array of doubles (device -> host copies at full PCIe rate instead of through a staging buffer)
 struct PinnedDoubles {
     double *p = nullptr;
-    size_t cap = 0, n = 0;
+    size_t cap = 0, n = 0, cap_prev = 0;
     hipError_t resize(size_t count)
     {
         if (count > cap) {
             if (p) (void)hipHostFree(p);
             p = nullptr; cap = 0;
-            hipError_t e = hipHostMalloc((void **)&p, (count ? count : 1) * sizeof(double), hipHostMallocDefault);
+            // (page-locking costs ~0.4 ms a call: grow geometrically, at least a page — the node batches of a BnB search double from round to round)
+            size_t want = count > 512 ? count : 512;
+            if (want < 2 * cap_prev) want = 2 * cap_prev;
+            hipError_t e = hipHostMalloc((void **)&p, want * sizeof(double), hipHostMallocDefault);
             if (e != hipSuccess) return e;
-            cap = count;
+            cap = cap_prev = want;
         }
         n = count;
         return hipSuccess;
@@ -56,7 +59,10 @@ struct partls_knobs {
     bool no_export = false;      // PARTLS_NO_EXPORT: the winner is always solved again from the empty basis (A/B tests)
     bool eager_generic = false;  // PARTLS_EAGER_GENERIC: n > 320 on sweep_generic.hip (every block applied to the whole tableau) instead of sweep_lazy.hip (A/B tests)
     int bnb_batch = 1024;        // PARTLS_BNB_BATCH: nodes bounded per device batch of the BnB search
-    int bnb_pool_mb = 16384;     // PARTLS_BNB_POOL_MB: cap of the tableau-snapshot pool of the BnB search (warm-started node bounds)
+    int bnb_pool_mb = 65536;     // PARTLS_BNB_POOL_MB: cap of the tableau-snapshot pool of the BnB search (warm-started node bounds); chunks are allocated on
+                                 // demand, never beyond half of the free HBM.  16 GB (round 3) ran out in the 173 717-node search of bench.py's bnb_hard: the
+                                 // late rounds then bounded a sixth of their nodes from the fresh tableau (47 pivots per node instead of 5.7) and took 3x longer
+    int bnb_wg_per_cu = 8;       // PARTLS_BNB_WG_PER_CU: workgroups per resident slot in a node batch's grid (1: persistent; 8: one node per workgroup as in round 3)
     bool bnb_cold = false;       // PARTLS_BNB_COLD: every BnB node from the fresh tableau (A/B tests)
     int coop_fault = 0;          // PARTLS_COOP_FAULT (tests): make the cooperative kernel's grid barrier time out (see SweepParams)
     bool no_tab_refine = false;  // PARTLS_NO_TAB_REFINE: refinement by host Cholesky even when the node solve left its tableau (A/B tests)
@@ -107,8 +113,7 @@ struct partls_ctx {
     std::vector<double> hPart, hGpart;             // host staging of a data pass
     // called between the Gram build and the tableau preparation (partls_fit_opt_multi: the Gram products of the row blocks are summed)
     std::function<partls_status(partls_ctx *)> gram_hook;
-    std::vector<uint64_t> bnbHostIn;
-    std::vector<char> bnbHostOut;
+    partls::PinnedDoubles bnbHostIn, bnbHostOut;   // page-locked staging of a node batch (8-byte words): the two copies of a round cost ~10 us each instead of ~25 pageable
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
     std::vector<double> hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)

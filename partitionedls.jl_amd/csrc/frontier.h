@@ -15,8 +15,53 @@
 // also keeps the reference counts of the snapshots (two children per branched node) and tells each rank which of ITS slots died.
 struct partls_frontier {
     struct Node { double key; uint64_t pat, free_; unsigned long long seq; int owner, slot; };
-    struct Cmp { bool operator()(const Node &a, const Node &b) const { return a.key > b.key || (a.key == b.key && a.seq > b.seq); } };
-    std::priority_queue<Node, std::vector<Node>, Cmp> heap;
+    // The open nodes, ordered by (parent's bound, sequence number).  The two children of a branched node carry the same key and
+    // consecutive sequence numbers, so they leave the heap together: ONE entry stands for both (`bit` = the branched group; -1: a single
+    // node — the root, or a child whose sibling went into the previous round), and the heap is 4-ary (a sift-down touches 3 cache lines per
+    // level and half the levels of a binary heap).  Round 4: with std::priority_queue<Node> popping and dealing a round of 1024 nodes cost
+    // 170 us against 200 us of device work for the same round.
+    struct Entry { double key; unsigned long long seq; uint64_t pat, free_; int owner, slot, bit, pad; };
+    struct Heap {
+        std::vector<Entry> a;
+        static bool less(const Entry &x, const Entry &y) { return x.key < y.key || (x.key == y.key && x.seq < y.seq); }
+        bool empty() const { return a.empty(); }
+        size_t size() const { return a.size(); }
+        const Entry &top() const { return a[0]; }
+        void push(const Entry &e)
+        {
+            a.push_back(e);
+            size_t i = a.size() - 1;
+            while (i > 0) {
+                const size_t par = (i - 1) >> 2;
+                if (!less(e, a[par])) break;
+                a[i] = a[par];
+                i = par;
+            }
+            a[i] = e;
+        }
+        void pop()
+        {
+            const Entry e = a.back();
+            a.pop_back();
+            const size_t n = a.size();
+            if (n == 0) return;
+            size_t i = 0;
+            for (;;) {
+                const size_t c0 = 4 * i + 1;
+                if (c0 >= n) break;
+                size_t m = c0;
+                const size_t ce = c0 + 4 < n ? c0 + 4 : n;
+                for (size_t c = c0 + 1; c < ce; ++c) if (less(a[c], a[m])) m = c;
+                if (!less(a[m], e)) break;
+                a[i] = a[m];
+                i = m;
+            }
+            a[i] = e;
+        }
+        // compatibility with the round-3 call sites: a single node
+        void push_node(const Node &nd) { push(Entry{nd.key, nd.seq, nd.pat, nd.free_, nd.owner, nd.slot, -1, 0}); }
+    };
+    Heap heap;
     int rank = 0, world = 1;
     int64_t batch = 1024, bounded = 0;
     unsigned long long seq = 0;
@@ -27,6 +72,7 @@ struct partls_frontier {
     std::vector<int> assign;                         // rank of every node of the round
     std::vector<char> warm;                          // it starts from its parent's snapshot there
     std::vector<int> dead;                           // this rank's slots that lost their last reference
+    std::vector<int64_t> load;                       // nodes dealt to every rank in the current round
 
     void unref(int owner, int slot)
     {
@@ -43,15 +89,22 @@ struct partls_frontier {
     int64_t next(int64_t *mine, uint64_t *pat, uint64_t *fre, int32_t *src, int32_t *per_rank)
     {
         round.clear();
-        while (!heap.empty() && (int64_t)round.size() < batch * world) {
-            const Node nd = heap.top();
+        const int64_t want = batch * world;
+        while (!heap.empty() && (int64_t)round.size() < want) {
+            const Entry e = heap.top();
             heap.pop();
-            if (nd.key >= mu) { unref(nd.owner, nd.slot); continue; }        // its bound can only be >= the parent's
-            round.push_back(nd);
+            const bool pair = e.bit >= 0;
+            if (e.key >= mu) { unref(e.owner, e.slot); if (pair) unref(e.owner, e.slot); continue; }   // a bound can only be >= the parent's
+            if (!pair) { round.push_back(Node{e.key, e.pat, e.free_, e.seq, e.owner, e.slot}); continue; }
+            const uint64_t bitm = 1ULL << e.bit;
+            round.push_back(Node{e.key, e.pat | bitm, e.free_, e.seq, e.owner, e.slot});              // alpha_pk >= 0 first (BnB.jl:120,123)
+            const Node second{e.key, e.pat & ~bitm, e.free_, e.seq + 1, e.owner, e.slot};            // alpha_pk <= 0
+            if ((int64_t)round.size() < want) round.push_back(second);
+            else heap.push_node(second);                                        // the round is full: it competes again, as a single node
         }
         const int64_t cnt = (int64_t)round.size();
         const int64_t quota = (cnt + world - 1) / world;
-        std::vector<int64_t> load((size_t)world, 0);
+        load.assign((size_t)world, 0);
         assign.assign((size_t)cnt, -1);
         warm.assign((size_t)cnt, 0);
         for (int64_t i = 0; i < cnt; ++i) {
@@ -98,8 +151,8 @@ struct partls_frontier {
             const uint64_t bit = 1ULL << k;
             if (d >= 0) setref(me, d, 2);                                     // both children start from this node's tableau
             const int o = d >= 0 ? me : -1, sl = d >= 0 ? d : -1;
-            heap.push({l, nd.pat | bit, nd.free_ & ~bit, seq++, o, sl});      // alpha_pk >= 0 first (BnB.jl:120,123)
-            heap.push({l, nd.pat & ~bit, nd.free_ & ~bit, seq++, o, sl});     // alpha_pk <= 0
+            heap.push(Entry{l, seq, nd.pat, nd.free_ & ~bit, o, sl, k, 0});   // both children: pat | bit (seq), pat & ~bit (seq + 1)
+            seq += 2;
         }
         round.clear();
     }

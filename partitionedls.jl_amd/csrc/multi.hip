@@ -463,7 +463,7 @@ void rank_bnb(partls_multi *mc, int r, const FitArgs &a)
             f.rank = r; f.world = R; f.batch = batch;
             f.refs.resize((size_t)R);
             f.best_free = ((uint64_t)1 << Kp) - 1;
-            f.heap.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, f.seq++, -1, -1});     // root: everything free (Σ = [], BnB.jl:33)
+            f.heap.push_node({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, f.seq++, -1, -1});     // root: everything free (Σ = [], BnB.jl:33)
             bp.resize((size_t)batch); bf.resize((size_t)batch); src.resize((size_t)batch); dst.resize((size_t)batch); br.resize((size_t)batch);
             lb.resize((size_t)batch); per_rank.resize((size_t)R);
             glb.resize((size_t)batch * R); gbr.resize((size_t)batch * R); gdst.resize((size_t)batch * R);

@@ -124,18 +124,20 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 4 * 4096)));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
     PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
-    c->bnbHostIn.resize(in_words);
-    std::memcpy(c->bnbHostIn.data(), pat, cnt * 8);
-    std::memcpy(c->bnbHostIn.data() + cnt, free_, cnt * 8);
+    PARTLS_HIP_CHECK(c->bnbHostIn.resize(in_words));
+    PARTLS_HIP_CHECK(c->bnbHostOut.resize((out_bytes + 7) / 8));
+    uint64_t *hin = reinterpret_cast<uint64_t *>(c->bnbHostIn.data());
+    std::memcpy(hin, pat, cnt * 8);
+    std::memcpy(hin + cnt, free_, cnt * 8);
     if (snaps) {
         for (size_t i = 0; i < cnt; ++i) {
-            c->bnbHostIn[2 * cnt + i] = (uint64_t)(uintptr_t)(src ? src[i] : nullptr);
-            c->bnbHostIn[3 * cnt + i] = (uint64_t)(uintptr_t)(dst ? dst[i] : nullptr);
+            hin[2 * cnt + i] = (uint64_t)(uintptr_t)(src ? src[i] : nullptr);
+            hin[3 * cnt + i] = (uint64_t)(uintptr_t)(dst ? dst[i] : nullptr);
         }
     }
     uint64_t *din = c->bnbIn.as<uint64_t>();
     char *dout = static_cast<char *>(c->bnbOut.p);
-    PARTLS_HIP_CHECK(hipMemcpyAsync(din, c->bnbHostIn.data(), in_words * 8, hipMemcpyHostToDevice, c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(din, hin, in_words * 8, hipMemcpyHostToDevice, c->stream));
     PARTLS_HIP_CHECK(hipMemsetAsync(dout, 0, 32, c->stream));
     PARTLS_HIP_CHECK(launch_bnb_codes(c->maskTabP, n, din, din + cnt, (int)cnt, c->nodeCode.as<int8_t>(), c->stream));
     SweepParams p{};
@@ -155,17 +157,22 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
         p.node_dst = reinterpret_cast<double *const *>(din + 3 * cnt);
     }
     p.T0 = c->T0reg.as<double>();
-    PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, (int)std::min<size_t>(cnt, 2048), c->stream));
+    // the 512-thread kernel runs one workgroup per CU at a time: a grid of one workgroup per CU (each walking cnt / CUs nodes) spares the
+    // later nodes the workgroup launch and the LDS image's initialisation; the 256-thread kernel (T <= 10) holds several per CU
+    int ncu = 256;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+    const size_t wg_cap = (size_t)ncu * (size_t)std::max(1, sweep_reg_concurrency(c->T)) * (size_t)std::max(1, c->knobs.bnb_wg_per_cu);
+    PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, (int)std::min<size_t>(cnt, wg_cap), c->stream));
     double *dlb = reinterpret_cast<double *>(dout + 32);
     int *dbr = reinterpret_cast<int *>(dout + 32 + cnt * 8);
     PARTLS_HIP_CHECK(launch_bnb_nu(p.node_sol, p.node_obj2, n, c->scale.as<double>(), c->maskTabP, Kp, din + cnt, (int)cnt, dlb, dbr, c->stream));
-    c->bnbHostOut.resize(out_bytes);
+    const char *hout = reinterpret_cast<const char *>(c->bnbHostOut.data());
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->bnbHostOut.data(), dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     unsigned long long counters[4];
-    std::memcpy(counters, c->bnbHostOut.data(), 32);
-    std::memcpy(lb, c->bnbHostOut.data() + 32, cnt * 8);
-    std::memcpy(branch, c->bnbHostOut.data() + 32 + cnt * 8, cnt * 4);
+    std::memcpy(counters, hout, 32);
+    std::memcpy(lb, hout + 32, cnt * 8);
+    std::memcpy(branch, hout + 32 + cnt * 8, cnt * 4);
     if (unconv) *unconv = counters[0];
     c->last_pivots = counters[1]; c->last_vetoes = counters[2];
     return PARTLS_OK;
@@ -435,6 +442,7 @@ try {
     if (c->bnbSlotBytes != ((snapshot_bytes(c) + 255) & ~(size_t)255)) { set_error("partls_bnb_bound_snap: call partls_bnb_snap_begin after preparing the problem"); return PARTLS_ERR_STATE; }
     std::vector<const double *> srcp((size_t)count);
     std::vector<double *> dstp((size_t)count);
+    const auto tr0 = std::chrono::steady_clock::now();
     for (int64_t i = 0; i < count; ++i) {
         if (src_slot[i] >= 0 && !pool.valid(src_slot[i])) { set_error("partls_bnb_bound_snap: src_slot[%lld] = %d is no slot of this context", (long long)i, src_slot[i]); return PARTLS_ERR_BAD_ARG; }
         dst_slot[i] = free_[i] ? pool.alloc() : -1;
@@ -442,7 +450,13 @@ try {
         dstp[(size_t)i] = dst_slot[i] >= 0 ? pool.ptr(dst_slot[i]) : nullptr;
     }
     unsigned long long unc = 0;
+    const auto tr1 = std::chrono::steady_clock::now();
     partls_status st = bnb_bound_batch(c, (size_t)count, pat, free_, srcp.data(), dstp.data(), lb, branch, &unc);
+    if (getenv("PARTLS_BNB_TRACE")) {
+        const auto tr2 = std::chrono::steady_clock::now();
+        const double a = std::chrono::duration<double, std::milli>(tr1 - tr0).count(), b = std::chrono::duration<double, std::milli>(tr2 - tr1).count();
+        if (a + b > 0.5) fprintf(stderr, "[bnb] batch of %lld: slots %.3f ms, device %.3f ms, chunks %zu\n", (long long)count, a, b, c->bnbChunks.size());
+    }
     if (st == PARTLS_OK && unc) { set_error("partls_bnb_bound_snap: a node bound hit the pivot cap"); st = PARTLS_ERR_NOT_CONVERGED; }
     if (st != PARTLS_OK) {
         // the host never learns these slots (it must not trust outputs of a failed call): back to the free list, or the pool would
@@ -534,7 +548,7 @@ try {
     f.batch = std::max(1, c->knobs.bnb_batch);
     f.refs.resize(1);
     f.best_free = ((uint64_t)1 << Kp) - 1;
-    f.heap.push({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, f.seq++, -1, -1});     // root: everything free (Σ = [], BnB.jl:33)
+    f.heap.push_node({0.0, 0ULL, ((uint64_t)1 << Kp) - 1, f.seq++, -1, -1});     // root: everything free (Σ = [], BnB.jl:33)
     partls_status st = partls_bnb_snap_begin(c);
     if (st != PARTLS_OK) return st;
     const size_t cap = (size_t)f.batch;
@@ -542,21 +556,32 @@ try {
     std::vector<int32_t> src(cap), dst(cap), br(cap);
     std::vector<double> lb(cap);
     int32_t per_rank = 0;
+    const bool trace = getenv("PARTLS_BNB_TRACE") != nullptr;
+    double t_next = 0.0, t_bound = 0.0, t_ingest = 0.0;
+    int rounds = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     while (!(max_nodes > 0 && f.bounded >= max_nodes)) {
         int64_t mine = 0;
+        const auto q0 = now();
         const int64_t cnt = f.next(&mine, bp.data(), bf.data(), src.data(), &per_rank);
+        const auto q1 = now();
         if (cnt > 0) {
             st = partls_bnb_bound_snap(c, cnt, bp.data(), bf.data(), src.data(), dst.data(), lb.data(), br.data());
             if (st != PARTLS_OK) return st;
-            f.ingest(lb.data(), br.data(), dst.data());
         }
+        const auto q2 = now();
+        if (cnt > 0) f.ingest(lb.data(), br.data(), dst.data());
         if (!f.dead.empty()) {
             st = partls_bnb_snap_release(c, (int64_t)f.dead.size(), f.dead.data());
             if (st != PARTLS_OK) return st;
             f.dead.clear();
         }
+        t_next += ms(q0, q1); t_bound += ms(q1, q2); t_ingest += ms(q2, now()); ++rounds;
         if (cnt == 0) break;
     }
+    if (trace) fprintf(stderr, "[bnb] search: %d rounds, %lld nodes: frontier pop / deal %.2f ms, device batches %.2f ms, ingest / release %.2f ms\n", rounds,
+                       (long long)f.bounded, t_next, t_bound, t_ingest);
     *mu_out = f.mu; *pat_out = f.best_pat; *free_out = f.best_free;
     if (nodes_out) *nodes_out = f.bounded;
     return PARTLS_OK;
@@ -574,7 +599,7 @@ try {
     f->rank = rank; f->world = world; f->batch = batch;
     f->refs.resize((size_t)world);
     f->best_free = ((uint64_t)1 << n_groups) - 1;
-    f->heap.push({0.0, 0ULL, ((uint64_t)1 << n_groups) - 1, f->seq++, -1, -1});
+    f->heap.push_node({0.0, 0ULL, ((uint64_t)1 << n_groups) - 1, f->seq++, -1, -1});
     *out = f;
     return PARTLS_OK;
 }

@@ -74,6 +74,12 @@ __device__ __forceinline__ double fast_rcp(double d)
     y = fma(fma(-d, y, 1.0), y, y);
     return y;
 }
+template <class PT> __device__ __forceinline__ PT *uniform_ptr(PT *p)     // a wave-uniform pointer the compiler cannot prove uniform -> SGPR pair
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (PT *)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
 __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane: wave-uniform
 {
@@ -332,8 +338,19 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 if (snap) src = snap;
             }
         }
+        // One wave-uniform base per PAIR of slots, opaque to the optimiser, + the thread's constant element offset + an immediate: left
+        // alone, LLVM hoists the CNT per-slot address offsets out of the chain loop as CNT live VGPRs, spills them, and every load / store of
+        // a chain start or snapshot then waits for its own scratch reload (`scratch_load; s_waitcnt vmcnt(0); global_store` 76 times: 35 us
+        // per snapshot, 85 % of a warm-started BnB node — found in the round-4 kernel trace of the node batches)
+        {
+            const double *bp = uniform_ptr(src) + (size_t)L::OFF * 256;
 #pragma unroll
-        for (int s = 0; s < L::CNT; ++s) S[s] = src[(size_t)(s + L::OFF) * 256 + t8];
+            for (int s = 0; s < L::CNT; ++s) {
+                if ((s & 1) == 0) asm volatile("" : "+s"(bp));
+                S[s] = bp[(s & 1) * 256 + t8];
+                if (s & 1) bp += 512;
+            }
+        }
         q = (tid < 16 * T) ? src[(size_t)nslots(T) * 256 + tid] : 0.0;
         corner = src[(size_t)nslots(T) * 256 + 16 * T];
         basic = false;
@@ -569,8 +586,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             if (p.node_dst) {                                     // snapshot of the final state: what a child node starts from
                 double *snap = p.node_dst[chain];
                 if (snap && (H == 0 || T > 1)) {
+                    {
+                        double *bp = uniform_ptr(snap) + (size_t)L::OFF * 256;  // (addresses as at the chain start: see there)
 #pragma unroll
-                    for (int s = 0; s < L::CNT; ++s) snap[(size_t)(s + L::OFF) * 256 + t8] = S[s];
+                        for (int s = 0; s < L::CNT; ++s) {
+                            if ((s & 1) == 0) asm volatile("" : "+s"(bp));
+                            bp[(s & 1) * 256 + t8] = S[s];
+                            if (s & 1) bp += 512;
+                        }
+                    }
                     if (tid < 16 * T) {
                         snap[(size_t)nslots(T) * 256 + tid] = q;
                         reinterpret_cast<int8_t *>(snap + (nslots(T) * 256 + 16 * T + 8))[tid] = basic ? 1 : 0;
@@ -580,8 +604,15 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
             }
             if (p.node_tab && (H == 0 || T > 1)) {                // final tableau + basis, same layout as T0 (half 1 of T = 1 owns nothing)
                 double *tab = p.node_tab + (size_t)chain * (nslots(T) * 256 + 16 * T + 8);
+                {
+                    double *bp = uniform_ptr(tab) + (size_t)L::OFF * 256;
 #pragma unroll
-                for (int s = 0; s < L::CNT; ++s) tab[(size_t)(s + L::OFF) * 256 + t8] = S[s];
+                    for (int s = 0; s < L::CNT; ++s) {
+                        if ((s & 1) == 0) asm volatile("" : "+s"(bp));
+                        bp[(s & 1) * 256 + t8] = S[s];
+                        if (s & 1) bp += 512;
+                    }
+                }
                 if (tid < 16 * T) p.node_basic[(size_t)chain * 16 * T + tid] = basic ? 1 : 0;
             }
         }

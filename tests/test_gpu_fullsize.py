@@ -143,3 +143,26 @@ def test_c5_bnb_equals_opt(partls):
     np.testing.assert_allclose(ab, ao, atol=1e-7)
     np.testing.assert_allclose(bb, bo_, atol=1e-7)
     assert nopen < (1 << K) // 64                             # the bound prunes: far fewer nodes than patterns
+
+
+def test_c5_bnb_on_a_target_that_branches_equals_opt(partls):
+    """bench.py's `bnb_hard` leg (C5 shape, y = 1 + noise: no feature carries signal, the relaxation is never feasible near the root and
+    the search bounds ~170 000 nodes): the incumbent the best-first search proves optimal equals the minimum of the full 2^24 enumeration
+    of the same problem (BnB.jl:94-132 vs Opt.jl:85-96), model included."""
+    seed, N, D, K = 20260005, 100_000, 256, 24
+    ctx, dX, dy, P, ws = _device_problem(partls, seed, N, D, K)
+    ctx.synth_device(seed, N, D, np.zeros(D), dX.data_ptr(), dy.data_ptr())
+    import torch
+    torch.cuda.synchronize()
+    ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, 0)
+    bo, bp, _, unconv = ctx.opt_sweep(0, -1)
+    assert unconv == 0
+    ao, bo_, to, oo, bio = ctx.opt_finish(bp)
+    ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+    mu, pat, free, nodes = ctx.bnb_search(0)
+    ab, bb, tb, ob = ctx.bnb_leaf(pat, free)
+    assert nodes > 10_000                                     # it really had to branch
+    assert abs(ob - oo) <= 1e-9 * oo and abs(mu - oo) <= 1e-9 * oo
+    yb = ab * bb[np.argmax(P, axis=1)]; yo = ao * bo_[np.argmax(P, axis=1)]     # the fitted weights (alpha of a zero-sum group is arbitrary)
+    np.testing.assert_allclose(yb, yo, atol=1e-7)
+    assert abs(tb - to) <= 1e-7
