@@ -246,6 +246,10 @@ typedef enum {
     PARTLS_T_COUNT = 5
 } partls_timer;
 partls_status partls_get_timing(const partls_ctx *ctx, partls_timer which, double *ms);
+/* host -> device upload of X inside the last prepare / fit on this context: wall time (ms) and bytes (0 / 0 when the inputs were device
+ * pointers).  A host X larger than 8 MB is staged through page-locked buffers by four copier threads (42-55 GB/s on a 57 GB/s link
+ * whatever the array's history; a plain copy from pageable memory pays for the pinning first: 8-25 GB/s on a fresh array). */
+partls_status partls_get_upload(const partls_ctx *ctx, double *ms, double *bytes);
 /* principal pivots executed by the last partls_opt_sweep (fp64 flop accounting: each pivot updates the whole symmetric tableau) */
 partls_status partls_get_pivots(const partls_ctx *ctx, int64_t *pivots);
 /* entering pivots the last partls_opt_sweep refused under the leave-one-out dependence rule (0 on well-conditioned data; a

@@ -69,6 +69,7 @@ SYMBOLS = [
     ("partls_synth_truth", C.c_int, [C.c_uint64, _i64, _i64, _ip, _dp]),
     ("partls_synth_device", C.c_int, [C.c_void_p, C.c_uint64, _i64, _i64, _dp, C.c_void_p, C.c_void_p]),
     ("partls_get_timing", C.c_int, [C.c_void_p, C.c_int, _dp]),
+    ("partls_get_upload", C.c_int, [C.c_void_p, _dp, _dp]),
     ("partls_get_gram", C.c_int, [C.c_void_p, _dp]),
     ("partls_get_pivots", C.c_int, [C.c_void_p, _ip]),
     ("partls_get_vetoes", C.c_int, [C.c_void_p, _ip]),

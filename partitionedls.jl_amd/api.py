@@ -259,6 +259,12 @@ class Context:
         _check(L.lib().partls_get_timing(self._h, int(which), C.byref(ms)))
         return ms.value
 
+    def upload(self):
+        """(ms, bytes) of the host -> device upload of X inside the last prepare / fit (0, 0: device-resident inputs)"""
+        ms = C.c_double(); b = C.c_double()
+        _check(L.lib().partls_get_upload(self._h, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
+
     def pivots(self):
         n = C.c_int64()
         _check(L.lib().partls_get_pivots(self._h, C.byref(n)))

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <numeric>
 #include <new>
+#include <thread>
 
 namespace partls {
 
@@ -71,6 +72,82 @@ double h_reg(const partls_ctx *c, int a, int b)
     return v;
 }
 
+// Host -> device copy of a column-major matrix (N x M, leading dimension ldX) into a packed device image (leading dimension N).
+// Measured on the MI355X box (tools/ubench/h2d_paths.hip, profiles/r04_h2d_paths.txt): the link gives 57 GB/s from page-locked memory;
+// hipMemcpy2DAsync from PAGEABLE memory reaches that only when the runtime has pinned the very same pages before — a caller's fresh
+// array goes at 8 GB/s (205 MB, C3) to 25 GB/s (4.1 GB, C4), the pinning itself costs as much as the transfer.  Staged through
+// page-locked buffers by a few copier threads the same array goes at 42-55 GB/s whatever its history: UP_T threads, each with its own
+// stream and two staging buffers, own a contiguous range of columns; a thread packs a batch of columns into one buffer (memcpy) while
+// the DMA of its previous batch runs from the other.  Small matrices (< 8 MB) take the plain copy.
+namespace {
+constexpr int UP_T = 4;
+constexpr size_t UP_BUF = (size_t)8 << 20;
+}
+static partls_status upload_matrix(partls_ctx *c, double *dst, const double *X, int64_t N, int64_t M, int64_t ldX)
+{
+    const size_t bytes = (size_t)N * M * sizeof(double);
+    if (bytes < ((size_t)8 << 20) || c->knobs.no_staged_upload) {
+        PARTLS_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double), (size_t)N * sizeof(double), (size_t)M,
+                                          hipMemcpyHostToDevice, c->stream));
+        return PARTLS_OK;
+    }
+    if (!c->upPin[0]) {
+        for (int i = 0; i < 2 * UP_T; ++i) PARTLS_HIP_CHECK(hipHostMalloc((void **)&c->upPin[i], UP_BUF, hipHostMallocDefault));
+        for (int t = 0; t < UP_T; ++t) PARTLS_HIP_CHECK(hipStreamCreateWithFlags(&c->upStream[t], hipStreamNonBlocking));
+        for (int i = 0; i < 2 * UP_T; ++i) PARTLS_HIP_CHECK(hipEventCreateWithFlags(&c->upEvent[i], hipEventDisableTiming));
+    }
+    // rows per piece of a column (a column longer than a staging buffer goes in pieces), columns per batch otherwise
+    const size_t col_bytes = (size_t)N * sizeof(double);
+    hipError_t err[UP_T];
+    for (int t = 0; t < UP_T; ++t) err[t] = hipSuccess;
+    const int device = c->device;
+    auto worker = [&](int t) {
+        hipError_t e = hipSetDevice(device);
+        const int64_t c0 = M * t / UP_T, c1 = M * (t + 1) / UP_T;
+        char *pin[2] = {c->upPin[2 * t], c->upPin[2 * t + 1]};
+        bool used[2] = {false, false};
+        int b = 0;
+        auto flush = [&](char *d, size_t n) {           // DMA of the buffer just filled; the other buffer is filled meanwhile
+            if (e == hipSuccess) e = hipMemcpyAsync(d, pin[b], n, hipMemcpyHostToDevice, c->upStream[t]);
+            if (e == hipSuccess) e = hipEventRecord(c->upEvent[2 * t + b], c->upStream[t]);
+            used[b] = true;
+            b ^= 1;
+            if (used[b] && e == hipSuccess) e = hipEventSynchronize(c->upEvent[2 * t + b]);      // the buffer about to be refilled is free again
+        };
+        if (col_bytes <= UP_BUF) {
+            const int64_t per = (int64_t)(UP_BUF / col_bytes);
+            for (int64_t j0 = c0; j0 < c1 && e == hipSuccess; j0 += per) {
+                const int64_t j1 = j0 + per < c1 ? j0 + per : c1;
+                for (int64_t j = j0; j < j1; ++j) std::memcpy(pin[b] + (size_t)(j - j0) * col_bytes, X + j * ldX, col_bytes);
+                flush(reinterpret_cast<char *>(dst + j0 * N), (size_t)(j1 - j0) * col_bytes);
+            }
+        } else {
+            const int64_t rows = (int64_t)(UP_BUF / sizeof(double));
+            for (int64_t j = c0; j < c1 && e == hipSuccess; ++j)
+                for (int64_t r0 = 0; r0 < N && e == hipSuccess; r0 += rows) {
+                    const int64_t r1 = r0 + rows < N ? r0 + rows : N;
+                    std::memcpy(pin[b], X + j * ldX + r0, (size_t)(r1 - r0) * sizeof(double));
+                    flush(reinterpret_cast<char *>(dst + j * N + r0), (size_t)(r1 - r0) * sizeof(double));
+                }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->upStream[t]);
+        err[t] = e;
+    };
+    {
+        std::vector<std::thread> th;
+        th.reserve(UP_T);
+        bool spawned = true;
+        try { for (int t = 1; t < UP_T; ++t) th.emplace_back(worker, t); }
+        catch (...) { spawned = false; }
+        worker(0);
+        for (std::thread &w : th) w.join();
+        if (!spawned) for (int t = (int)th.size() + 1; t < UP_T; ++t) worker(t);      // out of threads: the caller's thread takes the rest
+    }
+    PARTLS_HIP_CHECK(hipSetDevice(c->device));
+    for (int t = 0; t < UP_T; ++t) if (err[t] != hipSuccess) { set_error("staged upload of X failed: %s", hipGetErrorString(err[t])); return PARTLS_ERR_HIP; }
+    return PARTLS_OK;                                    // every copier has synchronised its stream: the image is complete for c->stream
+}
+
 partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, int64_t ldX, const double *y, int x_on_device,
                           const int64_t *P, int64_t K, int64_t ldP, double eta, bool faithful, uint32_t flags)
 {
@@ -81,6 +158,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     c->prepared = false;
     c->peers.clear();                              // a row-sharded fit sets them again after every rank has prepared its block
     c->near_for = -1; c->near_pat.clear(); c->cand.clear();
+    c->last_upload_ms = 0.0; c->last_upload_bytes = 0.0;
     c->sweep_vetoes = 0;
     c->coop_state_valid = false;
     c->order_ready = false; c->order_identity = true; c->flip_cost.clear(); c->ms[PARTLS_T_CALIB] = 0.0;
@@ -94,9 +172,12 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     } else {
         PARTLS_HIP_CHECK(c->ownX.ensure((size_t)N * M * sizeof(double)));
         PARTLS_HIP_CHECK(c->ownY.ensure((size_t)N * sizeof(double)));
-        PARTLS_HIP_CHECK(hipMemcpy2DAsync(c->ownX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double),
-                                          (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, c->stream));
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->ownY.p, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        const auto u0 = std::chrono::steady_clock::now();
+        st = upload_matrix(c, c->ownX.as<double>(), X, N, M, ldX);
+        if (st != PARTLS_OK) return st;
+        c->last_upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - u0).count();
+        c->last_upload_bytes = (double)N * (double)M * sizeof(double);
         c->dX = c->ownX.as<double>(); c->dy = c->ownY.as<double>(); c->ldX = N;
     }
 
@@ -682,6 +763,7 @@ try {
     if (const char *e = getenv("PARTLS_CAL_WS")) c->knobs.cal_ws = atof(e);
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
     c->knobs.no_export = getenv("PARTLS_NO_EXPORT") != nullptr;
+    c->knobs.no_staged_upload = getenv("PARTLS_NO_STAGED_UPLOAD") != nullptr;
     c->knobs.eager_generic = getenv("PARTLS_EAGER_GENERIC") != nullptr;
     c->knobs.bnb_cold = getenv("PARTLS_BNB_COLD") != nullptr;
     if (const char *e = getenv("PARTLS_BNB_BATCH")) c->knobs.bnb_batch = atoi(e);
@@ -728,6 +810,8 @@ void partls_destroy(partls_ctx *c)
         c->bnbChunks.clear();
         c->hG.release();
         c->bnbHostIn.release(); c->bnbHostOut.release();
+        for (int i = 0; i < 8; ++i) { if (c->upPin[i]) (void)hipHostFree(c->upPin[i]); if (c->upEvent[i]) (void)hipEventDestroy(c->upEvent[i]); }
+        for (int t = 0; t < 4; ++t) if (c->upStream[t]) (void)hipStreamDestroy(c->upStream[t]);
         if (c->hTab) (void)hipHostFree(c->hTab);
         if (c->hBasic) (void)hipHostFree(c->hBasic);
         for (int w = 0; w < PARTLS_T_COUNT; ++w) {
@@ -1220,8 +1304,8 @@ static partls_status predict_common(partls_ctx *c, const double *X, int64_t N, i
     if (!x_on_device) {
         PARTLS_HIP_CHECK(c->predX.ensure((size_t)N * M * sizeof(double)));
         PARTLS_HIP_CHECK(c->predY.ensure((size_t)N * sizeof(double)));
-        PARTLS_HIP_CHECK(hipMemcpy2DAsync(c->predX.p, (size_t)N * sizeof(double), X, (size_t)ldX * sizeof(double),
-                                          (size_t)N * sizeof(double), (size_t)M, hipMemcpyHostToDevice, c->stream));
+        const partls_status us = upload_matrix(c, c->predX.as<double>(), X, N, M, ldX);
+        if (us != PARTLS_OK) return us;
         dX = c->predX.as<double>(); ld = N; dyh = c->predY.as<double>();
     }
     PARTLS_HIP_CHECK(launch_residual(dX, N, M, ld, nullptr, c->wdev.as<double>(), t, nullptr, 1024, dyh, c->stream));
@@ -1294,6 +1378,14 @@ try {
     return PARTLS_OK;
 }
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+partls_status partls_get_upload(const partls_ctx *c, double *ms, double *bytes)
+try {
+    if (!c || !ms || !bytes) { set_error("partls_get_upload: bad argument"); return PARTLS_ERR_BAD_ARG; }
+    *ms = c->last_upload_ms; *bytes = c->last_upload_bytes;
+    return PARTLS_OK;
+}
 catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
 partls_status partls_get_pivots(const partls_ctx *c, int64_t *pivots)

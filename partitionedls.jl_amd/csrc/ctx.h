@@ -56,6 +56,7 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    bool no_staged_upload = false; // PARTLS_NO_STAGED_UPLOAD: host X goes up with one pageable hipMemcpy2DAsync, as through round 3 (A/B tests)
     bool no_export = false;      // PARTLS_NO_EXPORT: the winner is always solved again from the empty basis (A/B tests)
     bool eager_generic = false;  // PARTLS_EAGER_GENERIC: n > 320 on sweep_generic.hip (every block applied to the whole tableau) instead of sweep_lazy.hip (A/B tests)
     int bnb_batch = 1024;        // PARTLS_BNB_BATCH: nodes bounded per device batch of the BnB search
@@ -114,6 +115,12 @@ struct partls_ctx {
     // called between the Gram build and the tableau preparation (partls_fit_opt_multi: the Gram products of the row blocks are summed)
     std::function<partls_status(partls_ctx *)> gram_hook;
     partls::PinnedDoubles bnbHostIn, bnbHostOut;   // page-locked staging of a node batch (8-byte words): the two copies of a round cost ~10 us each instead of ~25 pageable
+    // staged upload of a host X (api.hip: upload_matrix): 4 copier threads x 2 page-locked buffers, one stream each; wall time and bytes of
+    // the last one (0 when the inputs were device-resident)
+    char *upPin[8] = {};
+    hipStream_t upStream[4] = {};
+    hipEvent_t upEvent[8] = {};
+    double last_upload_ms = 0.0, last_upload_bytes = 0.0;
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
     std::vector<double> hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)

@@ -45,7 +45,11 @@ static constexpr int MAXT = 20;                 // n <= 320 (T = 21 already runs
 #ifndef PARTLS_UPD_UNROLL
 #define PARTLS_UPD_UNROLL 1
 #endif
-static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks)
+static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks): the 256-thread kernel
+#ifndef PARTLS_MB_BIG
+#define PARTLS_MB_BIG 8
+#endif
+static constexpr int MBB = PARTLS_MB_BIG;       // ... of the 512-thread kernel (8..16; experiments: tools/experiments/README.md)
 static constexpr int NO_VETO = 99;
 
 constexpr int nslots(int T) { return T * (T + 1) / 2; }
@@ -128,9 +132,9 @@ struct LdsImageT {
 // the masks) sits in the first 64 KB, where base + element offset fits the 16-bit immediate of the ds_* instructions; with Z
 // behind the two panel buffers every operand read of the update loop needed its own v_add for the address.
 struct LdsImage {
-    double Z[MB * CWMAX];                      // [MB][CW] pivot column s as of its own step
-    double U[2 * (MB + 64)];                   // [2][MB+64] pivot-row entries of the current column (+ per-lane dummies)
-    double Dinv[MB + 64];                      // 1/d_s
+    double Z[MBB * CWMAX];                     // [MB][CW] pivot column s as of its own step
+    double U[2 * (MBB + 64)];                  // [2][MB+64] pivot-row entries of the current column (+ per-lane dummies)
+    double Dinv[MBB + 64];                     // 1/d_s
     unsigned long long s_inf[16];              // [2][8] violator mask of the scan
     unsigned long long s_bas[16];              // [2][8] basis mask of the scan
     unsigned s_sum[16];                        // [2][8] per-wave summary of s_inf: count | tile bits << 8
@@ -139,7 +143,7 @@ struct LdsImage {
     double s_best[4];                          // running minimum: obj^2, pattern (as bits); runner-up: obj^2, pattern
     unsigned char s_rbit[64];                  // reference bit of internal pattern bit b (exact ties only)
     unsigned long long s_vmask[16 * MAXT];     // group mask of variable v
-    double Pbase[2 * MB * CWMAX];              // [2][MB][CW] panel, double buffered by block parity
+    double Pbase[2 * MBB * CWMAX];             // [2][MB][CW] panel, double buffered by block parity
 };
 __shared__ LdsImage lds_image;
 __shared__ LdsImageT<CW_S, MAXT_S> lds_small;              // the 256-thread kernel's image (~51 KB: three workgroups per CU)
@@ -217,7 +221,7 @@ __device__ __forceinline__ void scatter_tile(SA &S, const double *P, int a, int 
 // loses the solution on ill-conditioned data (pivots ~1e-8: measured, tools/tableau_emul.py --block).
 // `my_basic`: this thread is a pivot row and its variable is basic (leaves).
 // Returns the first step whose entering pivot this thread's row vetoes under the leave-one-out rule (file header), M if none.
-template <int M, int CW>
+template <int M, int CW, int MBK>
 __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, double *Dinv, int myj, bool my_basic,
                                            double piv_eps, int tid, int prow, bool idle_wave)
 {
@@ -228,8 +232,8 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
         for (int s = 0; s < M; ++s) __syncthreads();
         return M;
     }
-    constexpr int US = MB + 64;                             // U row stride; slots MB.. are per-lane dummies (no same-address stores)
-    const int dummy = MB + (tid & 63);
+    constexpr int US = MBK + 64;                            // U row stride; slots MB.. are per-lane dummies (no same-address stores)
+    const int dummy = MBK + (tid & 63);
     double pv[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) pv[j] = P[j * CW + prow];
@@ -282,6 +286,7 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
     using L = Half<T, H, W>;
     constexpr int RS = L::RS, CW = L::CW, RHSPOS = 16 * RS, NW = (T + 3) / 4;      // NW: 64-bit mask words that can be non-empty
     constexpr int THREADS = L::NT;                                                  // shadows the namespace constant
+    constexpr int MB = W == 1 ? blk::MB : MBB;                                      // pivots per block of this kernel (shadows the namespace constant)
     static_assert(W == 2 || RHSPOS < 256, "the 256-thread kernel needs every panel row position (and the rhs row) below 256");
     auto &lds_image = *image_of<W>();
     const int tid = threadIdx.x, t8 = tid & 255, a = t8 & 15, b = t8 >> 4, lane = tid & 63, wave = tid >> 6;
@@ -479,14 +484,11 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                         {
                             int veto;
                             switch (m) {
-                                case 1: veto = panel_block<1, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                case 2: veto = panel_block<2, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                case 3: veto = panel_block<3, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                case 4: veto = panel_block<4, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                case 5: veto = panel_block<5, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                case 6: veto = panel_block<6, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                case 7: veto = panel_block<7, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
-                                default: veto = panel_block<8, CW>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
+#define PARTLS_PB(i) case i: if constexpr (i <= MB) veto = panel_block<(i <= MB ? i : 1), CW, MB>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); else veto = 0; break;
+                                PARTLS_PB(1) PARTLS_PB(2) PARTLS_PB(3) PARTLS_PB(4) PARTLS_PB(5) PARTLS_PB(6) PARTLS_PB(7) PARTLS_PB(8)
+                                PARTLS_PB(9) PARTLS_PB(10) PARTLS_PB(11) PARTLS_PB(12) PARTLS_PB(13) PARTLS_PB(14) PARTLS_PB(15)
+#undef PARTLS_PB
+                                default: veto = panel_block<MB, CW, MB>(P, Z, U, Dinv, myj, my_basic, p.piv_eps, tid, tid, idle_wave); break;
                             }
                             if (veto < m && tid != RHSPOS) atomicMin(&s_veto[bpar], veto);     // the rhs row is no variable
                         }

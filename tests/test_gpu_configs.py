@@ -325,3 +325,45 @@ def test_bnb_search_warm_two_ranks_on_one_device(partls, oracle):
     (mu1, pat1, free1, n1), opt1 = out[1]
     assert (pat0, free0, n0) == (pat1, free1, n1) and mu0 == mu1 and n0 > 30
     assert abs(opt0 - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(mu0 - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+
+
+def test_staged_upload_is_bit_identical_to_the_device_resident_path(partls, oracle, monkeypatch):
+    """A host X larger than 8 MB goes up through page-locked staging buffers (4 copier threads, column ranges): the device image, hence the
+    Gram products and everything after them, must be the one the plain copy and the device-resident path produce — with a leading
+    dimension, with columns longer than a staging buffer, and through predict."""
+    import torch
+    rng = np.random.default_rng(5)
+    for N, D, K, ld in ((70_000, 24, 4, 70_000), (60_001, 30, 5, 60_017), (1_200_000, 3, 2, 1_200_000)):
+        Xbig = np.asfortranarray(rng.standard_normal((ld, D)))
+        X = Xbig[:N]                                                            # F-ordered view with leading dimension ld
+        P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+        y = X @ (rng.random(D) * (np.arange(D) % K - 1.5)) + 0.1 * rng.standard_normal(N)
+        L = partls.lowlevel
+        ctx = partls.Context(0)
+        lib = L.lib()
+        import ctypes as C
+        Pf = np.asfortranarray(P)
+        def prep(flag_env):
+            assert lib.partls_opt_prepare(ctx._h, Xbig.ctypes.data, N, D, ld, y.ctypes.data, 0, Pf.ctypes.data, K, D, 0.0, 0) == L.OK
+            ctx._shape = (N, D, K)
+            return ctx.gram().copy(), ctx.upload()
+        G1, up1 = prep(None)
+        assert up1[1] == N * D * 8 and up1[0] > 0
+        dX = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()                 # column-major N x D on the device
+        dy = torch.from_numpy(y).cuda()
+        ctx.opt_prepare_device(dX.data_ptr(), dy.data_ptr(), N, D, N, P, 0.0, 0)
+        G2 = ctx.gram().copy()
+        assert ctx.upload() == (0.0, 0.0)
+        np.testing.assert_array_equal(G1, G2)
+        ctx.close()
+        monkeypatch.setenv("PARTLS_NO_STAGED_UPLOAD", "1")
+        ctx = partls.Context(0)
+        G3, _ = prep(None)
+        np.testing.assert_array_equal(G1, G3)
+        ctx.close()
+        monkeypatch.delenv("PARTLS_NO_STAGED_UPLOAD")
+    # predict through the staged upload
+    X = np.asfortranarray(rng.standard_normal((200_000, 8)))
+    P = np.zeros((8, 2), dtype=np.int64); P[:4, 0] = 1; P[4:, 1] = 1
+    model = partls.PartLSFitResult(rng.random(8), np.array([1.5, -2.0]), 0.25, P)
+    np.testing.assert_allclose(partls.predict(model, X), X @ (model.α * model.β[np.argmax(P, axis=1)]) + 0.25, rtol=0, atol=1e-12)
