@@ -191,9 +191,9 @@ def main():
         flops = res["pivots"] * (tiles * (tiles + 1) // 2) * 256 * 2
         fp64_tflops = flops / sweep_avg_s / 1e12
         # HBM traffic of one sweep launch: PMC counters cannot be read inside this process, so the per-launch figure is the one the
-        # round's rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS command measured (tools/profile_r03.sh -> profiles/)
+        # round's rocprofv3 FETCH_SIZE / WRITE_SIZE passes of THIS command measured (tools/profile_r0N.sh -> profiles/)
         traffic, tsrc = None, None
-        for tname in ("r03_sweep_traffic.json", "r02_sweep_traffic.json"):
+        for tname in ("r04_sweep_traffic.json", "r03_sweep_traffic.json", "r02_sweep_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if world == 1 and args.config == "C3" and not args.faithful and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]

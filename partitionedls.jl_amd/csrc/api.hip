@@ -773,6 +773,7 @@ try {
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
     c->knobs.alt_trace = getenv("PARTLS_ALT_TRACE") != nullptr;
+    c->knobs.alt_always_check = getenv("PARTLS_ALT_ALWAYS_CHECK") != nullptr;
     c->knobs.print_stamps = getenv("PARTLS_PRINT_STAMPS") != nullptr;
     // a failure below must not leak the context (or the objects already created)
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -804,7 +805,7 @@ void partls_destroy(partls_ctx *c)
                           &c->T0reg, &c->scratch, &c->bestObj, &c->bestPat, &c->counters, &c->allOpt, &c->wdev, &c->partial,
                           &c->yhatD, &c->gD, &c->nodeCode, &c->nodeSol, &c->nodeObj, &c->gridCtr,
                           &c->predX, &c->predY, &c->nodeTab, &c->nodeBasic, &c->altA, &c->altGA, &c->altHg,
-                          &c->nodePiv, &c->maskInt, &c->allOptRef, &c->bnbIn, &c->bnbOut};
+                          &c->nodePiv, &c->maskInt, &c->allOptRef, &c->bnbIn, &c->bnbOut, &c->altGersh};
         for (DevBuf *b : bufs) b->release();
         for (void *q : c->bnbChunks) (void)hipFree(q);
         c->bnbChunks.clear();

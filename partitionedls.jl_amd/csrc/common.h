@@ -134,6 +134,7 @@ hipError_t launch_bnb_codes(const uint64_t *mask_tab, int n, const uint64_t *pat
 hipError_t launch_bnb_nu(const double *sol, const double *obj2, int n, const double *scale, const uint64_t *mask_tab, int Kp,
                          const uint64_t *free_, int cnt, double *lb, int *branch, hipStream_t s);
 
+hipError_t launch_gersh(const double *Tfull, int n, double *out, hipStream_t s);   // Gershgorin radii of the scaled Gram block (n doubles)
 // residual from the data: out[0] = sum_i (sum_m X[i,m] w[m] + t - y[i])^2   (y may be nullptr -> plain prediction into yhat)
 // beta-step system of fit(Alt): Hg[k * (Kp + 1) + k2] = H[k][k2] (k2 < Kp), g[k] (k2 = Kp); GA is (M + 1) x Kp scratch
 hipError_t launch_alt_beta_system(const double *G, int ldg, int M, double eta, const uint64_t *mask_aug, const double *a, int Kp,

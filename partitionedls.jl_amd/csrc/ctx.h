@@ -69,6 +69,7 @@ struct partls_knobs {
     bool no_tab_refine = false;  // PARTLS_NO_TAB_REFINE: refinement by host Cholesky even when the node solve left its tableau (A/B tests)
     bool finish_trace = false;   // PARTLS_FINISH_TRACE
     bool alt_trace = false;      // PARTLS_ALT_TRACE
+    bool alt_always_check = false; // PARTLS_ALT_ALWAYS_CHECK: fit(Alt) verifies its last iteration against the data even when Gershgorin certifies the Gram form (tests)
     bool print_stamps = false;   // PARTLS_PRINT_STAMPS (diagnostic build only)
     double kkt_tol = 1e-12;      // PARTLS_KKT_TOL: data-space KKT violation of the winner (units of ||x_m|| ||y||) above which fit(Opt) / fit(BnB) report
                                  // PARTLS_ERR_ILL_CONDITIONED instead of PARTLS_OK (see kkt_says_ill_conditioned, api.hip)
@@ -103,7 +104,7 @@ struct partls_ctx {
     int ldg = 0, chunks = 0;
     partls::DevBuf slab, G, maskAugD /* + maskTabP, permP: one upload */, scale, Tfull, T0reg, scratch, bestObj, bestSol /* [workgroups][n]: solution of every workgroup's best pattern (register kernels) */, bestPat, counters, allOpt,
         wdev, partial, yhatD, gD, nodeCode, nodeSol, nodeObj, predX, predY, gridCtr, nodeTab, nodeBasic, altA, altGA, altHg,
-        nodePiv, maskInt, allOptRef, bnbIn, bnbOut;
+        nodePiv, maskInt, allOptRef, bnbIn, bnbOut, altGersh;
     // BnB: tableau snapshots of open nodes (solvers.hip: SnapshotPool), kept across fits; host staging of a node batch
     std::vector<void *> bnbChunks;
     size_t bnbSlotBytes = 0, bnbMaxSlots = 0;

@@ -217,6 +217,29 @@ __global__ __launch_bounds__(256) void bnb_nu_kernel(const double *__restrict__ 
     }
 }
 
+// Gershgorin radii of the scaled Gram block (unit diagonal): out[i] = sum_{j != i, j < n} |T[i][j]|.  max_i out[i] = r proves
+// lambda_min >= 1 - r and lambda_max <= 1 + r for the matrix every solve of the prepared problem works on (solvers.hip: fit(Alt) skips
+// its extra pass over X when that bound alone guarantees the Gram form's accuracy).
+__global__ __launch_bounds__(256) void gersh_kernel(const double *__restrict__ T, int n, int ld, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) if (j != i) s += fabs(T[(size_t)i * ld + j]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = red[0];
+}
+hipError_t launch_gersh(const double *Tfull, int n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(gersh_kernel, dim3(n), dim3(256), 0, s, Tfull, n, n + 1, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_bnb_codes(const uint64_t *mask_tab, int n, const uint64_t *pat, const uint64_t *free_, int cnt, int8_t *codes, hipStream_t s)
 {
     hipLaunchKernelGGL(bnb_codes_kernel, dim3(cnt), dim3(256), 0, s, mask_tab, n, pat, free_, codes);

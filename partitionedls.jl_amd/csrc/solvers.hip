@@ -214,6 +214,12 @@ try {
     };
     auto w_from = [&]() { feature_mul(); for (int m = 0; m < Mp; ++m) w[(size_t)m] = a[(size_t)m] * f[(size_t)m]; };
     std::vector<int8_t> codes((size_t)c->n);
+    // Gershgorin radii of the scaled Gram block (one tiny kernel now, read back with the first alpha-step's results): decides after the
+    // loop whether the last iteration must be verified against the data (see there)
+    std::vector<double> gersh((size_t)c->n, 0.0);
+    PARTLS_HIP_CHECK(c->altGersh.ensure((size_t)c->n * sizeof(double)));
+    PARTLS_HIP_CHECK(launch_gersh(c->Tfull.as<double>(), c->n, c->altGersh.as<double>(), c->stream));
+    PARTLS_HIP_CHECK(hipMemcpyAsync(gersh.data(), c->altGersh.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     // what the data-space check after the loop needs of the LAST iteration: the alpha-step's raw solution w = f∘α (before checkalpha and
     // the renormalisation), its constraint codes over [features, intercept], and the diagonal of the beta-step system
     std::vector<double> wv, hdiag((size_t)Kp, 0.0);
@@ -296,16 +302,31 @@ try {
     //     host Gram copy (error ~eps |B| |w - w_alpha|: exact at convergence, ~1e-13 when the beta-step still moves w by O(1)) instead
     //     of a second pass over X.
     // Above PARTLS_KKT_TOL the call returns PARTLS_ERR_ILL_CONDITIONED with the model in the outputs (INTEGRATION.md reroutes that
-    // status to the stock Julia body).  Cost: two reads of X per fit (1.7 ms of 4.1 GB at C4).
+    // status to the stock Julia body).
+    // WHEN the pass is needed.  It costs two reads of X (2.2 ms of a 6.9 ms fit at C4), and on well-conditioned data it can only confirm
+    // what perturbation theory already guarantees: the solves work on G~ (unit diagonal), and normal-equation solutions carry a relative
+    // error of at most ~n eps cond(G~).  Gershgorin gives a RIGOROUS bound from the matrix itself: with r = max_i sum_{j != i} |G~_ij|,
+    // lambda_min >= 1 - r and lambda_max <= 1 + r.  For r <= 0.75 (cond <= 7: n eps cond < 1e-12 up to n = 1023, the threshold of the check
+    // itself) the fit is certified without touching X again — Gaussian-like designs (C4: r = 0.41).  Anything else — correlated features,
+    // uncentred columns against the intercept, eta-coupled groups — takes the pass.  PARTLS_ALT_ALWAYS_CHECK forces it (tests).
+    double radius = 0.0;
+    for (int v = 0; v < c->n; ++v) radius = std::max(radius, gersh[(size_t)v]);
+    const bool certified = i > 1 && radius <= 0.75 && std::isfinite(radius) && !c->knobs.alt_always_check;
     double dopt = optval;
     std::vector<double> g;
-    st = data_objective(c, w, &dopt, &g);
-    if (st != PARTLS_OK) return st;
     c->last_kkt = 0.0;
     c->last_min_loo = 0.0;
     int worst = -1;
     const char *which = "";
-    if (i > 1 && unconv_total == 0) {                        // at least one iteration ran
+    if (certified) {
+        // the loss of the last iteration, beta'H beta - 2 g'beta + y'y from the K' x K' system, carries an absolute error of ~eps * y'y
+        // (cancellation against y'y): only a near-interpolating fit (the reference's toy: opt = 0) needs the objective from the data
+        if (!(optval * optval > 1e-6 * h_reg(c, Y, Y))) { st = data_objective(c, w, &dopt); if (st != PARTLS_OK) return st; }
+    } else {
+        st = data_objective(c, w, &dopt, &g);
+        if (st != PARTLS_OK) return st;
+    }
+    if (!certified && i > 1 && unconv_total == 0) {          // at least one iteration ran
         const double yy = h_reg(c, Y, Y), ynorm = std::sqrt(yy > 0.0 ? yy : 0.0);
         for (int k = 0; k < Kp; ++k) {
             double s = 0.0;

@@ -303,3 +303,30 @@ def test_refinement_by_tableau_inverse_equals_refinement_by_cholesky(partls, ora
             np.testing.assert_allclose(b1, b2, atol=1e-9 * max(1.0, np.abs(b2).max()))
             assert abs(t1 - t2) <= 1e-9 * max(1.0, abs(t2))
             assert abs(o1 - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+
+
+def test_alt_certificate_or_data_check(partls, oracle, monkeypatch):
+    """fit(Alt) on a Gaussian design: Gershgorin's bound on the scaled Gram block (radius < 0.75: cond <= 7) certifies the Gram-form solves
+    and the extra pass over X is skipped (kkt_violation reads exactly 0); with PARTLS_ALT_ALWAYS_CHECK the last iteration is verified
+    against the data instead (a tiny, non-zero violation).  Same model either way, equal to the oracle's dense Alt from the same start."""
+    rng = np.random.default_rng(11)
+    N, D, K = 20000, 30, 5
+    X = rng.standard_normal((N, D))
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    y = X @ (rng.random(D) * (np.arange(D) % K - 2.0)) + 0.3 * rng.standard_normal(N)
+    a0, b0 = rng.random(D + 1), (rng.random(K + 1) - 0.5) * 10
+    ref = oracle.fit_alt(X, y, P, a0, b0, eps=1e-9, T=50)
+    res = {}
+    for mode in ("certified", "checked"):
+        if mode == "checked":
+            monkeypatch.setenv("PARTLS_ALT_ALWAYS_CHECK", "1")
+        ctx = partls.Context(0)
+        ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+        res[mode] = ctx.alt_prepared(a0, b0, eps=1e-9, T=50) + (ctx.kkt_violation(),)
+        ctx.close()
+    assert res["certified"][5] == 0.0 and 0.0 < res["checked"][5] <= 1e-13
+    for mode in res:
+        a, b, t, opt, it, _ = res[mode]
+        assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+        np.testing.assert_allclose(a, ref["alpha"], atol=1e-7)
+    np.testing.assert_array_equal(res["certified"][0], res["checked"][0])
