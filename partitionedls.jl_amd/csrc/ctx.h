@@ -108,6 +108,7 @@ struct partls_ctx {
     // BnB: tableau snapshots of open nodes (solvers.hip: SnapshotPool), kept across fits; host staging of a node batch
     std::vector<void *> bnbChunks;
     size_t bnbSlotBytes = 0, bnbMaxSlots = 0;
+    int bnbChunkSlots = 512;
     std::vector<int> bnbFree, bnbRefs;             // free slots; reference counts of the in-library search (the ABI's host keeps its own)
     // rows of X sharded over several devices (partls_fit_opt_multi): the contexts that hold the OTHER row blocks of the problem this
     // context is prepared for; every pass over the data (data_pass, api.hip) then covers them too.  Cleared by every prepare.

@@ -58,9 +58,9 @@ bool solve_dense(std::vector<double> &H, std::vector<double> &g, int n)
 // its children start from the fresh tableau.
 struct SnapshotPool {                                              // a view of the pool state the context keeps (ctx.h: bnb*)
     partls_ctx *c;
-    static constexpr int CHUNK = 512;
     std::vector<int> &free_list, &refs;
     explicit SnapshotPool(partls_ctx *ctx) : c(ctx), free_list(ctx->bnbFree), refs(ctx->bnbRefs) {}
+    int chunk() const { return c->bnbChunkSlots; }                 // slots per hipMalloc: ~160 MB (512 slots at n = 257, 170 at n = 341, 19 at n = 1023)
 
     hipError_t begin(size_t bytes)
     {
@@ -69,29 +69,30 @@ struct SnapshotPool {                                              // a view of 
             for (void *q : c->bnbChunks) (void)hipFree(q);
             c->bnbChunks.clear();
             c->bnbSlotBytes = slot_bytes;
+            c->bnbChunkSlots = (int)std::max<size_t>(8, std::min<size_t>(512, ((size_t)160 << 20) / slot_bytes));
         }
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         size_t cap = (size_t)c->knobs.bnb_pool_mb << 20;
-        cap = std::min(cap, free_b / 2 + c->bnbChunks.size() * CHUNK * slot_bytes);
+        cap = std::min(cap, free_b / 2 + c->bnbChunks.size() * chunk() * slot_bytes);
         c->bnbMaxSlots = cap / slot_bytes;
         free_list.clear();
-        refs.assign(c->bnbChunks.size() * CHUNK, 0);
+        refs.assign(c->bnbChunks.size() * chunk(), 0);
         for (int i = (int)refs.size() - 1; i >= 0; --i) free_list.push_back(i);
         return hipSuccess;
     }
-    bool valid(int slot) const { return slot >= 0 && (size_t)slot < c->bnbChunks.size() * CHUNK; }
-    double *ptr(int slot) const { return reinterpret_cast<double *>(static_cast<char *>(c->bnbChunks[(size_t)slot / CHUNK]) + (size_t)(slot % CHUNK) * c->bnbSlotBytes); }
+    bool valid(int slot) const { return slot >= 0 && (size_t)slot < c->bnbChunks.size() * chunk(); }
+    double *ptr(int slot) const { return reinterpret_cast<double *>(static_cast<char *>(c->bnbChunks[(size_t)slot / chunk()]) + (size_t)(slot % chunk()) * c->bnbSlotBytes); }
     int alloc()                                                    // -1: pool exhausted
     {
         if (free_list.empty()) {
-            if ((c->bnbChunks.size() + 1) * CHUNK > c->bnbMaxSlots) return -1;
+            if ((c->bnbChunks.size() + 1) * chunk() > c->bnbMaxSlots) return -1;
             void *q = nullptr;
-            if (hipMalloc(&q, (size_t)CHUNK * c->bnbSlotBytes) != hipSuccess) { (void)hipGetLastError(); c->bnbMaxSlots = 0; return -1; }
-            const int base = (int)c->bnbChunks.size() * CHUNK;
+            if (hipMalloc(&q, (size_t)chunk() * c->bnbSlotBytes) != hipSuccess) { (void)hipGetLastError(); c->bnbMaxSlots = 0; return -1; }
+            const int base = (int)c->bnbChunks.size() * chunk();
             c->bnbChunks.push_back(q);
-            refs.resize((size_t)base + CHUNK, 0);
-            for (int i = CHUNK - 1; i >= 0; --i) free_list.push_back(base + i);
+            refs.resize((size_t)base + chunk(), 0);
+            for (int i = chunk() - 1; i >= 0; --i) free_list.push_back(base + i);
         }
         const int sl = free_list.back();
         free_list.pop_back();
@@ -102,7 +103,15 @@ struct SnapshotPool {                                              // a view of 
     void drop(int slot) { if (slot >= 0) free_list.push_back(slot); }          // a slot nobody references
 };
 
-size_t snapshot_bytes(const partls_ctx *c) { return sweep_reg_t0_doubles(c->T) * sizeof(double) + (size_t)16 * c->T; }
+// register kernel: the tile-cyclic image (tiles, rhs column, corner) + 16 T basis flags; deferred-update kernel (n > 320, sweep_lazy.hip):
+// [ld x ld] base image, [ld] rhs column + corner, [n] basis flags
+bool snapshots_supported(const partls_ctx *c) { return c->use_reg || !c->knobs.eager_generic; }
+size_t snapshot_bytes(const partls_ctx *c)
+{
+    if (c->use_reg) return sweep_reg_t0_doubles(c->T) * sizeof(double) + (size_t)16 * c->T;
+    const size_t ld = (size_t)c->n + 1;
+    return (ld * ld + ld) * sizeof(double) + (size_t)c->n;
+}
 
 // Bound `cnt` nodes (pat, free) on the register kernel: codes, node solves (warm-started from src[i] when given, final state
 // stored to dst[i] when given) and (bound, branch) all on the device; one upload, one download, one synchronisation per batch.
@@ -123,7 +132,14 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
     PARTLS_HIP_CHECK(c->nodeSol.ensure((4 + cnt + cnt * (size_t)n) * sizeof(double)));
     PARTLS_HIP_CHECK(c->bestObj.ensure(sizeof(double) * (4 + 4 * 4096)));
     PARTLS_HIP_CHECK(c->bestPat.ensure(sizeof(int64_t) * 4096));
-    PARTLS_HIP_CHECK(c->scratch.ensure(64 * sizeof(double)));
+    // workgroups of the batch's grid: the 512-thread kernel runs one per CU at a time and the dispatcher balances nodes of different cost
+    // best with one node per workgroup (tools/experiments/README.md); the global-memory kernel needs a scratch tableau per workgroup
+    int ncu = 256;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
+    const size_t wg_cap = c->use_reg ? (size_t)ncu * (size_t)std::max(1, sweep_reg_concurrency(c->T)) * (size_t)std::max(1, c->knobs.bnb_wg_per_cu)
+                                     : (size_t)2 * ncu;
+    const int grid = (int)std::min<size_t>(cnt, wg_cap);
+    PARTLS_HIP_CHECK(c->scratch.ensure(c->use_reg ? 64 * sizeof(double) : (size_t)grid * (n + 1) * (n + 1) * sizeof(double)));
     PARTLS_HIP_CHECK(c->bnbHostIn.resize(in_words));
     PARTLS_HIP_CHECK(c->bnbHostOut.resize((out_bytes + 7) / 8));
     uint64_t *hin = reinterpret_cast<uint64_t *>(c->bnbHostIn.data());
@@ -156,13 +172,13 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
         p.node_src = reinterpret_cast<const double *const *>(din + 2 * cnt);
         p.node_dst = reinterpret_cast<double *const *>(din + 3 * cnt);
     }
-    p.T0 = c->T0reg.as<double>();
-    // the 512-thread kernel runs one workgroup per CU at a time: a grid of one workgroup per CU (each walking cnt / CUs nodes) spares the
-    // later nodes the workgroup launch and the LDS image's initialisation; the 256-thread kernel (T <= 10) holds several per CU
-    int ncu = 256;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 1) ncu = 256;
-    const size_t wg_cap = (size_t)ncu * (size_t)std::max(1, sweep_reg_concurrency(c->T)) * (size_t)std::max(1, c->knobs.bnb_wg_per_cu);
-    PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, (int)std::min<size_t>(cnt, wg_cap), c->stream));
+    if (c->use_reg) {
+        p.T0 = c->T0reg.as<double>();
+        PARTLS_HIP_CHECK(launch_sweep_blk(p, c->T, grid, c->stream));
+    } else {
+        p.T0 = c->Tfull.as<double>();
+        PARTLS_HIP_CHECK(launch_sweep_lazy(p, grid, c->stream));
+    }
     double *dlb = reinterpret_cast<double *>(dout + 32);
     int *dbr = reinterpret_cast<int *>(dout + 32 + cnt * 8);
     PARTLS_HIP_CHECK(launch_bnb_nu(p.node_sol, p.node_obj2, n, c->scale.as<double>(), c->maskTabP, Kp, din + cnt, (int)cnt, dlb, dbr, c->stream));
@@ -382,7 +398,7 @@ try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (count < 0 || (count > 0 && (!pat || !free_ || !lb || !branch))) { set_error("partls_bnb_bound: bad argument"); return PARTLS_ERR_BAD_ARG; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
-    if (c->use_reg) {                                          // codes, solves and (bound, branch) on the device (misc.hip)
+    if (snapshots_supported(c)) {                              // codes, solves and (bound, branch) on the device (misc.hip)
         unsigned long long unc = 0;
         partls_status st2 = bnb_bound_batch(c, (size_t)count, pat, free_, nullptr, nullptr, lb, branch, &unc);
         if (st2 != PARTLS_OK) return st2;
@@ -441,7 +457,7 @@ partls_status partls_bnb_snap_begin(partls_ctx *c)
 try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_snap_begin: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
-    if (!c->use_reg) { c->bnbFree.clear(); c->bnbRefs.clear(); c->bnbMaxSlots = 0; return PARTLS_OK; }
+    if (!snapshots_supported(c)) { c->bnbFree.clear(); c->bnbRefs.clear(); c->bnbMaxSlots = 0; return PARTLS_OK; }
     SnapshotPool pool(c);
     PARTLS_HIP_CHECK(pool.begin(snapshot_bytes(c)));
     return PARTLS_OK;
@@ -454,7 +470,7 @@ partls_status partls_bnb_bound_snap(partls_ctx *c, int64_t count, const uint64_t
 try {
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound_snap: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (count < 0 || (count > 0 && (!pat || !free_ || !src_slot || !dst_slot || !lb || !branch))) { set_error("partls_bnb_bound_snap: bad argument"); return PARTLS_ERR_BAD_ARG; }
-    if (!c->use_reg || c->knobs.bnb_cold) {                    // no snapshots on the global-memory kernels
+    if (!snapshots_supported(c) || c->knobs.bnb_cold) {        // no snapshots on the eager global-memory kernel (A/B reference)
         for (int64_t i = 0; i < count; ++i) dst_slot[i] = -1;
         return partls_bnb_bound(c, count, pat, free_, lb, branch);
     }

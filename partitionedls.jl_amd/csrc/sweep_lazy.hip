@@ -337,7 +337,8 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     __shared__ unsigned long long s_inf[LZ_MAXWORDS];
     __shared__ int s_viol[LZ_MAXWORDS * 64];
 
-    double *T = p.scratch + (size_t)blockIdx.x * (size_t)ld * (size_t)ld;
+    double *const Tscratch = p.scratch + (size_t)blockIdx.x * (size_t)ld * (size_t)ld;
+    double *T = Tscratch;
     const int nwords = (n + 63) >> 6;
     const bool has_row = tid < ld;
     const uint64_t mymask = (tid < n && !p.node_code) ? p.mask[tid] : 0;   // group membership of this thread's variable (chain mode)
@@ -363,10 +364,24 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     for (int64_t chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
         const int64_t g0 = p.g_begin + chain * p.chain_len;
         const int64_t g1 = (g0 + p.chain_len < p.g_end) ? g0 + p.chain_len : p.g_end;
+        // Tableau SNAPSHOTS (node mode; round 4: BnB warm starts beyond the register kernel, BnB.jl:120-124).  A snapshot is the state a
+        // node solve ends in, with every pending term applied: [ld x ld] base image (upper triangle of the n x n block), [ld] rhs column +
+        // corner, [n] basis flags.  A node with a destination slot works IN that slot (its base image lives there from the start: one copy
+        // in, none out); its source is its parent's slot, or the fresh tableau.
+        const double *src = p.T0;
+        bool from_snap = false;
+        T = Tscratch;
+        if (p.node_code) {                                            // wave-uniform (kernel arguments and uniform loads)
+            if (p.node_dst && p.node_dst[chain]) T = p.node_dst[chain];
+            if (p.node_src && p.node_src[chain]) { src = p.node_src[chain]; from_snap = true; }
+        }
         for (int i = tid >> 6; i < n; i += NT / 64)                  // upper triangle only, whole 64-chunks
-            for (int c = (i & ~63) + lane; c < n; c += 64) T[(size_t)i * ld + c] = p.T0[(size_t)i * ld + c];
-        if (has_row) qs[tid] = p.T0[(size_t)tid * ld + n];
-        for (int i = tid; i < n; i += NT) { s_basic[i] = 0; s_blocked[i] = 0; }
+            for (int c = (i & ~63) + lane; c < n; c += 64) T[(size_t)i * ld + c] = src[(size_t)i * ld + c];
+        if (has_row) qs[tid] = from_snap ? src[(size_t)ld * ld + tid] : src[(size_t)tid * ld + n];
+        {
+            const uint8_t *fl = reinterpret_cast<const uint8_t *>(src + (size_t)ld * ld + ld);
+            for (int i = tid; i < n; i += NT) { s_basic[i] = from_snap ? fl[i] : 0; s_blocked[i] = 0; }
+        }
         int Rcur = 0;                                                         // pending terms (uniform)
         __threadfence_block();
         __syncthreads();
@@ -606,6 +621,17 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
             for (int i = tid; i < n; i += NT)
                 p.node_sol[(size_t)chain * p.node_ld + i] = s_basic[i] ? qs[i] : 0.0;
             if (tid == 0) p.node_obj2[chain] = qs[n];
+        }
+        if (p.node_code && T != Tscratch) {                          // the node leaves a snapshot: apply what is still pending, add q and the flags
+            if (Rcur > 0) {
+                if (tid < 4) dp[Rcur + tid] = 0.0;                    // padding of the last k-step
+                __syncthreads();
+                lz_flush<NT>(T, ld, n, Zp, dp, Rcur, tid);
+                Rcur = 0;
+            }
+            if (has_row) T[(size_t)ld * ld + tid] = qs[tid];
+            uint8_t *fl = reinterpret_cast<uint8_t *>(T + (size_t)ld * ld + ld);
+            for (int i = tid; i < n; i += NT) fl[i] = s_basic[i];
         }
         __syncthreads();
     }

@@ -124,11 +124,59 @@ def test_free_intercept_sharded_and_deterministic(partls, oracle, monkeypatch):
 
 
 def test_bnb_node_batches_beyond_320(partls, oracle):
-    """fit(BnB) at n = 331: node batches run in node mode on the deferred-update kernel (cold starts: snapshots exist only for the
-    register kernel); BnB optimum = Opt optimum = oracle (BnB.jl:94-132 explores the same sign patterns)."""
+    """fit(BnB) at n = 331: node batches run in node mode on the deferred-update kernel (warm-started from the parent's snapshot since
+    round 4); BnB optimum = Opt optimum = oracle (BnB.jl:94-132 explores the same sign patterns)."""
     X, y, P = _problem(5001, 800, 330, 4, noise=1.0)
     mb, _, rb = partls.fit(partls.BnB, X, y, P)
     mo, _, ro = partls.fit(partls.Opt, X, y, P)
     ref = oracle.fit_opt(X, y, P)
     assert abs(rb.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(ro.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
     np.testing.assert_allclose(partls.predict(mb, X), partls.predict(mo, X), atol=1e-6 * np.linalg.norm(y))
+
+
+def _branching_large(seed, N, D, K):
+    """a target the partitioned model cannot explain: unconstrained signs inside every group, so the relaxation mixes signs and BnB branches"""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    y = X @ (rng.standard_normal(D) * (rng.random(D) < 0.5)) + 0.5 * rng.standard_normal(N)
+    return np.asfortranarray(X), y, np.asfortranarray(P)
+
+
+@pytest.mark.parametrize("D,K", [(330, 6), (520, 4)])
+def test_bnb_warm_starts_beyond_320_equal_cold_ones(partls, oracle, monkeypatch, D, K):
+    """BnB node bounds beyond the register kernel start from the PARENT's tableau (a snapshot of the deferred-update kernel's state: base
+    image with every pending term applied + rhs column + basis flags, BnB.jl:120-124) — same bounds, same branching, hence the same
+    search (node for node) and the same optimum as with every node solved from the fresh tableau (PARTLS_BNB_COLD), in far fewer pivots.
+    D = 330: ld mod 64 < 16 (the lane-mask corner of round 3); D = 520: the 1024-thread plan."""
+    X, y, P = _branching_large(77, 900, D, K)
+    res = {}
+    for mode in ("warm", "cold"):
+        if mode == "cold":
+            monkeypatch.setenv("PARTLS_BNB_COLD", "1")
+        monkeypatch.setenv("PARTLS_BNB_BATCH", "16")
+        ctx = partls.Context(0)
+        try:
+            ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+            mu, pat, free, nodes = ctx.bnb_search(0)
+            # one batch by hand: the children of the root, warm against cold, bound for bound
+            ctx.bnb_snap_begin()
+            lb0, br0, dst0 = ctx.bnb_bound_snap(np.array([0], dtype=np.uint64), np.array([(1 << (K + 1)) - 1], dtype=np.uint64), np.array([-1], dtype=np.int32))
+            piv_root = ctx.pivots()
+            k = int(br0[0]); bit = 1 << k; fr = ((1 << (K + 1)) - 1) & ~bit
+            lb1, br1, dst1 = ctx.bnb_bound_snap(np.array([bit, 0], dtype=np.uint64), np.array([fr, fr], dtype=np.uint64), np.array([dst0[0], dst0[0]], dtype=np.int32))
+            piv_children = ctx.pivots()
+            a, b, t, opt = ctx.bnb_leaf(pat, free)
+            res[mode] = dict(mu=mu, pat=pat, free=free, nodes=nodes, lb1=lb1.copy(), br1=br1.copy(), dst0=int(dst0[0]), piv_root=piv_root, piv_children=piv_children, opt=opt)
+        finally:
+            ctx.close()
+    w, c = res["warm"], res["cold"]
+    assert w["nodes"] > 8 and k >= 0
+    assert w["dst0"] >= 0 and c["dst0"] == -1                                  # snapshots are taken beyond n = 320 now; not in cold mode
+    assert (w["pat"], w["free"], w["nodes"]) == (c["pat"], c["free"], c["nodes"])
+    assert abs(w["mu"] - c["mu"]) <= 1e-10 * c["mu"] and abs(w["opt"] - c["opt"]) <= 1e-10 * c["opt"]
+    np.testing.assert_allclose(w["lb1"], c["lb1"], rtol=1e-10)
+    np.testing.assert_array_equal(w["br1"], c["br1"])
+    assert w["piv_children"] * 4 < c["piv_children"], (w["piv_children"], c["piv_children"])      # a child exchanges one group, not half the variables
+    ref = oracle.fit_bnb(X, y, P)
+    assert abs(w["opt"] - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
