@@ -62,6 +62,10 @@ struct partls_frontier {
         void push_node(const Node &nd) { push(Entry{nd.key, nd.seq, nd.pat, nd.free_, nd.owner, nd.slot, -1, 0}); }
     };
     Heap heap;
+    // Entries popped AHEAD of the next round, while the device bounds the current one (prefetch()): a small heap of its own (it stays in
+    // cache), merged with the big heap's top by next() — so the round is exactly what popping after the ingest would have given (children
+    // pushed meanwhile compete through the big heap), and the expensive sift-downs of the big heap overlap the device's work.
+    Heap staged;
     int rank = 0, world = 1;
     int64_t batch = 1024, bounded = 0;
     unsigned long long seq = 0;
@@ -90,9 +94,10 @@ struct partls_frontier {
     {
         round.clear();
         const int64_t want = batch * world;
-        while (!heap.empty() && (int64_t)round.size() < want) {
-            const Entry e = heap.top();
-            heap.pop();
+        while ((!heap.empty() || !staged.empty()) && (int64_t)round.size() < want) {
+            const bool from_staged = !staged.empty() && (heap.empty() || Heap::less(staged.top(), heap.top()));
+            const Entry e = from_staged ? staged.top() : heap.top();
+            if (from_staged) staged.pop(); else heap.pop();
             const bool pair = e.bit >= 0;
             if (e.key >= mu) { unref(e.owner, e.slot); if (pair) unref(e.owner, e.slot); continue; }   // a bound can only be >= the parent's
             if (!pair) { round.push_back(Node{e.key, e.pat, e.free_, e.seq, e.owner, e.slot}); continue; }
@@ -127,6 +132,13 @@ struct partls_frontier {
         for (int q = 0; q < world; ++q) per_rank[q] = (int32_t)load[(size_t)q];
         *mine = m;
         return cnt;
+    }
+    // pops up to a round's worth of entries out of the big heap ahead of time (no pruning, no reference counting: next() does both when it
+    // takes them); call it between the launch of a round's device work and the wait for it
+    void prefetch()
+    {
+        const size_t want = (size_t)(batch * world);
+        while (!heap.empty() && staged.size() < want) { staged.push(heap.top()); heap.pop(); }
     }
     // results of the round in RANK-MAJOR order (rank 0's nodes in the order next() gave them to rank 0, then rank 1's, ...)
     void ingest(const double *lb, const int32_t *br, const int32_t *dst)

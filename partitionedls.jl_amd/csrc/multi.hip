@@ -488,6 +488,7 @@ void rank_bnb(partls_multi *mc, int r, const FitArgs &a)
         double *slot = mc->xbuf[round & 1].data() + (size_t)r * stride;
         slot[0] = st == PARTLS_OK ? 0.0 : 1.0; slot[1] = (double)total; slot[2] = (double)mine;
         for (int64_t i = 0; i < mine; ++i) { slot[4 + i] = lb[(size_t)i]; slot[4 + batch + i] = (double)br[(size_t)i]; slot[4 + 2 * batch + i] = (double)dst[(size_t)i]; }
+        f.prefetch();                                           // the next round's pops, while the slower ranks finish this one
         if (!mc->bar.wait()) { lost(mc, r); return; }
         bool ok = true, same = true;
         for (int q = 0; q < R; ++q) {

@@ -116,7 +116,8 @@ size_t snapshot_bytes(const partls_ctx *c)
 // Bound `cnt` nodes (pat, free) on the register kernel: codes, node solves (warm-started from src[i] when given, final state
 // stored to dst[i] when given) and (bound, branch) all on the device; one upload, one download, one synchronisation per batch.
 partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, const uint64_t *free_, const double *const *src,
-                              double *const *dst, double *lb, int32_t *branch, unsigned long long *unconv)
+                              double *const *dst, double *lb, int32_t *branch, unsigned long long *unconv,
+                              const std::function<void()> &between = {})
 {
     const int n = c->n, Kp = (int)c->K + 1;
     c->tab_valid = false;
@@ -182,9 +183,10 @@ partls_status bnb_bound_batch(partls_ctx *c, size_t cnt, const uint64_t *pat, co
     double *dlb = reinterpret_cast<double *>(dout + 32);
     int *dbr = reinterpret_cast<int *>(dout + 32 + cnt * 8);
     PARTLS_HIP_CHECK(launch_bnb_nu(p.node_sol, p.node_obj2, n, c->scale.as<double>(), c->maskTabP, Kp, din + cnt, (int)cnt, dlb, dbr, c->stream));
-    const char *hout = reinterpret_cast<const char *>(c->bnbHostOut.data());
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->bnbHostOut.data(), dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (between) between();                                  // host work that overlaps the batch (the search pops its next round here)
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const char *hout = reinterpret_cast<const char *>(c->bnbHostOut.data());
     unsigned long long counters[4];
     std::memcpy(counters, hout, 32);
     std::memcpy(lb, hout + 32, cnt * 8);
@@ -465,14 +467,26 @@ try {
 catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
 catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
 
+static partls_status bnb_bound_snap_impl(partls_ctx *c, int64_t count, const uint64_t *pat, const uint64_t *free_, const int32_t *src_slot,
+                                         int32_t *dst_slot, double *lb, int32_t *branch, const std::function<void()> &between);
 partls_status partls_bnb_bound_snap(partls_ctx *c, int64_t count, const uint64_t *pat, const uint64_t *free_, const int32_t *src_slot,
                                     int32_t *dst_slot, double *lb, int32_t *branch)
 try {
+    return bnb_bound_snap_impl(c, count, pat, free_, src_slot, dst_slot, lb, branch, {});
+}
+catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
+catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
+static partls_status bnb_bound_snap_impl(partls_ctx *c, int64_t count, const uint64_t *pat, const uint64_t *free_, const int32_t *src_slot,
+                                         int32_t *dst_slot, double *lb, int32_t *branch, const std::function<void()> &between)
+{
     if (!c || !c->prepared || !c->faithful) { set_error("partls_bnb_bound_snap: needs a context prepared with PARTLS_OPT_FAITHFUL_INTERCEPT"); return PARTLS_ERR_STATE; }
     if (count < 0 || (count > 0 && (!pat || !free_ || !src_slot || !dst_slot || !lb || !branch))) { set_error("partls_bnb_bound_snap: bad argument"); return PARTLS_ERR_BAD_ARG; }
     if (!snapshots_supported(c) || c->knobs.bnb_cold) {        // no snapshots on the eager global-memory kernel (A/B reference)
         for (int64_t i = 0; i < count; ++i) dst_slot[i] = -1;
-        return partls_bnb_bound(c, count, pat, free_, lb, branch);
+        const partls_status cs = partls_bnb_bound(c, count, pat, free_, lb, branch);
+        if (between) between();
+        return cs;
     }
     PARTLS_HIP_CHECK(hipSetDevice(c->device));
     SnapshotPool pool(c);
@@ -488,7 +502,7 @@ try {
     }
     unsigned long long unc = 0;
     const auto tr1 = std::chrono::steady_clock::now();
-    partls_status st = bnb_bound_batch(c, (size_t)count, pat, free_, srcp.data(), dstp.data(), lb, branch, &unc);
+    partls_status st = bnb_bound_batch(c, (size_t)count, pat, free_, srcp.data(), dstp.data(), lb, branch, &unc, between);
     if (getenv("PARTLS_BNB_TRACE")) {
         const auto tr2 = std::chrono::steady_clock::now();
         const double a = std::chrono::duration<double, std::milli>(tr1 - tr0).count(), b = std::chrono::duration<double, std::milli>(tr2 - tr1).count();
@@ -503,8 +517,7 @@ try {
     }
     return PARTLS_OK;
 }
-catch (const std::bad_alloc &) { partls::set_error("out of host memory"); return PARTLS_ERR_BAD_ARG; }
-catch (...) { partls::set_error("internal error: an exception reached the C ABI"); return PARTLS_ERR_BAD_ARG; }
+
 
 partls_status partls_bnb_snap_release(partls_ctx *c, int64_t count, const int32_t *slots)
 try {
@@ -604,7 +617,8 @@ try {
         const int64_t cnt = f.next(&mine, bp.data(), bf.data(), src.data(), &per_rank);
         const auto q1 = now();
         if (cnt > 0) {
-            st = partls_bnb_bound_snap(c, cnt, bp.data(), bf.data(), src.data(), dst.data(), lb.data(), br.data());
+            // while the device bounds this round the host pops the next one out of the big heap (merged with the new children by next())
+            st = bnb_bound_snap_impl(c, cnt, bp.data(), bf.data(), src.data(), dst.data(), lb.data(), br.data(), [&f]() { f.prefetch(); });
             if (st != PARTLS_OK) return st;
         }
         const auto q2 = now();
