@@ -770,6 +770,7 @@ try {
     if (const char *e = getenv("PARTLS_BNB_POOL_MB")) c->knobs.bnb_pool_mb = atoi(e);
     if (const char *e = getenv("PARTLS_BNB_WG_PER_CU")) c->knobs.bnb_wg_per_cu = atoi(e);
     if (const char *e = getenv("PARTLS_COOP_FAULT")) c->knobs.coop_fault = atoi(e);
+    c->knobs.lz_fault = getenv("PARTLS_LZ_FAULT") != nullptr;
     c->knobs.no_tab_refine = getenv("PARTLS_NO_TAB_REFINE") != nullptr;
     c->knobs.finish_trace = getenv("PARTLS_FINISH_TRACE") != nullptr;
     c->knobs.alt_trace = getenv("PARTLS_ALT_TRACE") != nullptr;
@@ -1032,6 +1033,7 @@ try {
     p.n_unconverged = c->bestObj.as<unsigned long long>();
     p.n_pivots = c->bestObj.as<unsigned long long>() + 1;
     p.n_vetoes = c->bestObj.as<unsigned long long>() + 2;
+    if (!c->use_reg && c->knobs.lz_fault) p.coop_fault = 77;   // test hook of the deferred-update kernel's panel (SweepParams::coop_fault)
     for (int k = 0; k < 40; ++k) p.rbit.gbit[k] = (uint8_t)k;
     if (!c->order_identity) for (int k = 0; k < c->kbits; ++k) p.rbit.gbit[c->order.gbit[k]] = (uint8_t)k;   // exact ties: first REFERENCE index
     // the register kernels leave the solution of every workgroup's best pattern behind: partls_opt_finish starts from the winner's

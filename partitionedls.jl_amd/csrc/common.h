@@ -82,7 +82,8 @@ struct SweepParams {
     int resume;
     unsigned *grid_ctr;          // multi-workgroup kernel: arrival counter [0] and abort word [1] of its grid barrier (zeroed by the launcher)
     int coop_fault;              // test hook (PARTLS_COOP_FAULT): the grid barrier expects this many arrivals too many, i.e. it can
-                                 // only time out — exercises the abort word and the host's one-workgroup fallback
+                                 // only time out — exercises the abort word and the host's one-workgroup fallback.  77 in a launch of the deferred-update
+                                 // kernel (PARTLS_LZ_FAULT): workgroup 0's first two-phase panel never publishes its progress word
 };
 
 // launchers (each returns hipError_t of the launch)

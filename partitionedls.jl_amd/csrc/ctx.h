@@ -65,6 +65,8 @@ struct partls_knobs {
                                  // late rounds then bounded a sixth of their nodes from the fresh tableau (47 pivots per node instead of 5.7) and took 3x longer
     int bnb_wg_per_cu = 8;       // PARTLS_BNB_WG_PER_CU: workgroups per resident slot in a node batch's grid (1: persistent; 8: one node per workgroup as in round 3)
     bool bnb_cold = false;       // PARTLS_BNB_COLD: every BnB node from the fresh tableau (A/B tests)
+    bool lz_fault = false;       // PARTLS_LZ_FAULT (tests): the deferred-update kernel's first panel of workgroup 0 loses its progress word — the followers' bounded
+                                 // wait must end it and the sweep must report PARTLS_ERR_NOT_CONVERGED instead of a result
     int coop_fault = 0;          // PARTLS_COOP_FAULT (tests): make the cooperative kernel's grid barrier time out (see SweepParams)
     bool no_tab_refine = false;  // PARTLS_NO_TAB_REFINE: refinement by host Cholesky even when the node solve left its tableau (A/B tests)
     bool finish_trace = false;   // PARTLS_FINISH_TRACE

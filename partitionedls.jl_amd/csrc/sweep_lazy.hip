@@ -177,7 +177,7 @@ template <int NT, int MT>
 __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ dinv,
                                                   double *__restrict__ tab, double *__restrict__ red, const int *__restrict__ ks, int m_,
                                                   int ld_, uint8_t *__restrict__ s_basic, int myj, unsigned basm_, double piv_eps, int tid,
-                                                  unsigned long long &nveto, unsigned long long *stk = nullptr)
+                                                  unsigned long long &nveto, unsigned long long *stk = nullptr, bool drop_progress = false)
 {
 #ifdef PARTLS_LZ_STAMPS
     unsigned long long pt0 = __builtin_readcyclecounter();
@@ -234,7 +234,8 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
                 // the LDS executes one wave's operations in order: the progress word cannot become visible before the table row written
                 // above it — no s_waitcnt needed, only the compiler must keep the order
                 asm volatile("" ::: "memory");
-                if (lane == 0) __hip_atomic_store(prog, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (drop_progress: fault injection, PARTLS_LZ_FAULT — the word is never written, every follower runs into the bound of its wait)
+                if (lane == 0 && !drop_progress) __hip_atomic_store(prog, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane < m) Zn[s * ld + krow1] = zi;
                 // row update  pp[c] = fma(u_{4g+c}, -zi / d, pp[c]); the pivot row itself becomes u |1/d| = fma(u, |1/d|, 0): the same
                 // instruction with its own multiplier and a zeroed addend
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
     long long second_pat = -1;
     unsigned long long npiv = 0, nunconv = 0, nveto = 0;
     double wg_best2 = __builtin_inf();                            // objective^2 of the pattern whose solution sits in p.best_sol (the same in every thread)
+    bool lz_fault = p.coop_fault == 77 && blockIdx.x == 0;       // test hook: workgroup 0's first block loses its progress word (see lz_panel_eliminate)
 
 #ifdef PARTLS_LZ_STAMPS
     unsigned long long lz_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lz_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, lz_last = __builtin_readcyclecounter();
@@ -521,10 +523,12 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     double *Zn = Zp + (size_t)Rcur * ld, *dn = dp + Rcur;
                     int acc_piv;
                     if constexpr (NT <= 512) {
-                        acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK)
-                                         : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK);
+                        acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK, lz_fault)
+                                         : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK, lz_fault);
+                        lz_fault = false;
                     } else if constexpr (NT <= LZ_TWO_PHASE_MAX_NT) {         // 128 VGPRs per thread: blocks of at most 8 pivots (lazy_plan), the narrow panel only
-                        acc_piv = lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK);
+                        acc_piv = lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK, lz_fault);
+                        lz_fault = false;
                     } else {                                                  // 128 VGPRs per thread: the step-by-step form (two barriers per pivot, few registers)
                         acc_piv = gj_panel_eliminate<NT>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, p.piv_eps, tid);
                     }

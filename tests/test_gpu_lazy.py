@@ -180,3 +180,27 @@ def test_bnb_warm_starts_beyond_320_equal_cold_ones(partls, oracle, monkeypatch,
     assert w["piv_children"] * 4 < c["piv_children"], (w["piv_children"], c["piv_children"])      # a child exchanges one group, not half the variables
     ref = oracle.fit_bnb(X, y, P)
     assert abs(w["opt"] - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+
+
+def test_a_lost_progress_word_ends_in_not_converged_not_in_a_hang(partls, monkeypatch):
+    """The two-phase panel's followers wait for the progress word of the wave that runs phase 1 — a bounded wait (2^22 polls).  Fault
+    injection (PARTLS_LZ_FAULT): workgroup 0's first panel never publishes the word.  The kernel must finish (every wave reaches the bound
+    and walks on), and the sweep must not pass the garbage off as a result: the unconverged count is raised, fit() raises status 6."""
+    import time
+    X, y, P = _problem(31, 600, 330, 3)
+    monkeypatch.setenv("PARTLS_LZ_FAULT", "1")
+    ctx = partls.Context(0)
+    try:
+        ctx.opt_prepare(X, y, P, 0.0, 0)
+        t0 = time.time()
+        bo, bp, _, unconv = ctx.opt_sweep(0, -1)
+        assert unconv >= 1 and time.time() - t0 < 60.0
+    finally:
+        ctx.close()
+    monkeypatch.delenv("PARTLS_LZ_FAULT")
+    ctx = partls.Context(0)
+    try:
+        ctx.opt_prepare(X, y, P, 0.0, 0)
+        assert ctx.opt_sweep(0, -1)[3] == 0
+    finally:
+        ctx.close()
