@@ -609,14 +609,30 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     for (int it = 0; it < steps; ++it) {
         bool spd = true;
         // residual (and squared residual) and gradient on the device(s); the Cholesky factorisation, when it is needed, overlaps with them
-        partls_status dst = data_pass(c, w, out != nullptr, true, &obj2_pre, &g, [&]() { if (it == 0 && !use_tab) spd = factorise(); });
+        partls_status dst = data_pass(c, w, out != nullptr, true, &obj2_pre, &g, {});
         if (dst != PARTLS_OK) return dst;
         if (out) {
             eta_terms(c, w, &obj2_pre, nullptr);
             std::fill(delta.begin(), delta.end(), 0.0);
         }
-        if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
         eta_terms(c, w, nullptr, &g);                        // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
+        if (!use_tab && it == 0) {
+            // Is there anything to correct?  On data the Gram form resolves, the data-space gradient on the support is rounding noise already
+            // (C2: 2.6e-16 of ||x|| ||y||, the correction 6e-16 of |w|): then the p^3 / 6 factorisation — 0.1 ms at p = 129, half of the
+            // whole finish of a C2-sized fit — buys nothing.  Below 1e-14 the solution's error along the weakest direction is below
+            // cond * 1e-14 (cond <= ~100 for the gradient to be that small at all): the pass's objective and gradient ARE the result.
+            const double yy = h_reg(c, (int)M + 1, (int)M + 1);
+            double gmax = 0.0;
+            for (int i = 0; i < p; ++i) {
+                const int m = sup[(size_t)i];
+                const double dd = h_reg(c, m, m);
+                gmax = std::max(gmax, (dd > 0.0 && yy > 0.0) ? std::fabs(g[(size_t)m]) / std::sqrt(dd * yy) : (g[(size_t)m] != 0.0 ? 1.0 : 0.0));
+            }
+            if (c->knobs.finish_trace) fprintf(stderr, "[refine] max |g_S| / (|x||y|) of the Gram-form solution = %.3e%s\n", gmax, gmax <= 1e-14 ? ": nothing to correct" : "");
+            if (gmax <= 1e-14) { if (out) finish_out(); break; }
+            spd = factorise();
+        }
+        if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
         if (use_tab) {
             const int nb = (int)tabsup.size();
             const bool elim = !c->faithful;                  // free intercept: rhs and solution go through its Schur complement
@@ -684,6 +700,12 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         }
         double dn = 0.0, wn = 0.0;
         for (int i = 0; i < p; ++i) { w[(size_t)sup[(size_t)i]] += d[(size_t)i]; dn += d[(size_t)i] * d[(size_t)i]; wn += w[(size_t)sup[(size_t)i]] * w[(size_t)sup[(size_t)i]]; if (out) delta[(size_t)sup[(size_t)i]] = d[(size_t)i]; }
+        if (c->knobs.finish_trace) {
+            double gmax = 0.0;
+            const double yy = h_reg(c, (int)M + 1, (int)M + 1);
+            for (int i = 0; i < p; ++i) { const int m = sup[(size_t)i]; const double dd = h_reg(c, m, m); if (dd > 0.0 && yy > 0.0) gmax = std::max(gmax, std::fabs(g[(size_t)m]) / std::sqrt(dd * yy)); }
+            fprintf(stderr, "[refine] step %d (Cholesky): |delta|/|w| = %.3e, max |g_S| / (|x||y|) before it = %.3e\n", it, std::sqrt(dn / (wn > 0 ? wn : 1)), gmax);
+        }
         // the iteration contracts by cond^2 eps per step: once a correction is below 1e-9 relative, the next one is below
         // round-off for every problem the Gram path can solve at all
         if (dn <= 1e-18 * wn) { if (out) finish_out(); break; }
