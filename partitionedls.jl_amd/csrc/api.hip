@@ -1062,7 +1062,7 @@ try {
     // instead of solving that pattern again from the empty basis (C2: 89 us of a 0.58 ms fit)
     c->export_wg = -1;
     // (the 256-thread register kernel for small tableaus and the deferred-update kernel beyond n = 320; not the 512-thread kernel)
-    if (((c->use_reg && sweep_reg_small(c->T)) || (!c->use_reg && !c->knobs.eager_generic)) && !c->knobs.no_export) {
+    if (((c->use_reg && (sweep_reg_small(c->T) || sweep_reg_exports(c->T))) || (!c->use_reg && !c->knobs.eager_generic)) && !c->knobs.no_export) {
         PARTLS_HIP_CHECK(c->bestSol.ensure((size_t)grid * n * sizeof(double)));
         p.best_sol = c->bestSol.as<double>();
         p.node_ld = n;

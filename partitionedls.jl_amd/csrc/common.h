@@ -109,6 +109,7 @@ hipError_t launch_sweep_blk(const SweepParams &p, int T, int grid, hipStream_t s
 hipError_t launch_sweep_coop(const SweepParams &p, int nwg, hipStream_t s);   // one node, many workgroups (n > 320)
 bool       sweep_reg_supported(int n);
 int        sweep_reg_tiles(int n);
+bool       sweep_reg_exports(int T);                     // the 512-thread kernel of this build leaves its winner's solution behind as well
 bool       sweep_reg_small(int T);                       // T tile columns run on the 256-thread kernel (which also exports best_sol)
 size_t     sweep_reg_t0_doubles(int T);                  // size of the tile-cyclic initial tableau
 int        sweep_reg_concurrency(int T);                 // chains a CU runs at the same time (1: the 512-thread kernel, > 1: small tableaus)

@@ -46,9 +46,13 @@ static constexpr int MAXT = 20;                 // n <= 320 (T = 21 already runs
 #define PARTLS_UPD_UNROLL 1
 #endif
 static constexpr int MB = 8;                    // pivots per block (a tile column with more violators takes two blocks): the 256-thread kernel
+#ifndef PARTLS_EXPORT_BIG
+#define PARTLS_EXPORT_BIG 1      // the 512-thread kernel leaves the solution of every workgroup's best pattern behind (round 4: C3 finish 0.54 -> 0.16 ms, sweep 49.1 -> 48.6)
+#endif
 #ifndef PARTLS_MB_BIG
 #define PARTLS_MB_BIG 8
 #endif
+static constexpr int EXPORT_MAXT = 17;          // ... up to this tile count (beyond it the two live registers of the export start spilling: 22 -> 32 spilled VGPRs at T = 18)
 static constexpr int MBB = PARTLS_MB_BIG;       // ... of the 512-thread kernel (8..16; experiments: tools/experiments/README.md)
 static constexpr int NO_VETO = 99;
 
@@ -561,9 +565,9 @@ __device__ __forceinline__ void sweep_body(const SweepParams &p)
                 }
             }
             if (p.all_opt && tid == THREADS - 1) p.all_opt[pat] = sqrt(obj2);
-            if constexpr (!NODE && W == 1) {
-                // (256-thread kernel only: in the 512-thread kernel the two extra live registers move 8 spills and cost 1.8 % of the C3 sweep,
-                // against 0.15 ms of a 50 ms fit saved)
+            if constexpr (!NODE && (W == 1 || (PARTLS_EXPORT_BIG && T <= EXPORT_MAXT))) {
+                // (round 3: 256-thread kernel only — in the 512-thread kernel the two extra live registers moved 8 spills and cost 1.8 % of the
+                // C3 sweep.  Round 4: the spills turned out to be hoisted address offsets and are gone; -DPARTLS_EXPORT_BIG=1 measures it again)
                 // the workgroup's best pattern so far leaves its solution behind (rhs column of the basic variables, as node mode's
                 // node_sol): the host takes the winner's from here instead of solving that pattern again from the empty basis.  Every
                 // thread decides for itself on the replicated corner; on exact objective ties the FIRST pattern's solution stays (the
@@ -681,6 +685,7 @@ __global__ void layout_reg_kernel(const double *__restrict__ Tfull, int n, int T
 
 bool sweep_reg_supported(int n) { return n >= 1 && n <= 16 * blk::MAXT; }
 int sweep_reg_tiles(int n) { return (n + 15) / 16; }
+bool sweep_reg_exports(int T) { return PARTLS_EXPORT_BIG != 0 && T <= blk::EXPORT_MAXT; }
 bool sweep_reg_small(int T) { return T <= blk::MAXT_S; }   // the 256-thread kernel (several chains per CU) runs this tile count
 size_t sweep_reg_t0_doubles(int T) { return (size_t)T * (T + 1) / 2 * 256 + 16 * (size_t)T + 8; }
 
