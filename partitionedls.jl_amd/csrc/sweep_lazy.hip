@@ -316,7 +316,9 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
     return __popc(accm);
 }
 
-template <int NT>
+// NODE: node mode (BnB bounds, Alt alpha-steps, calibration walks) is its own instantiation: only there can the base image live in a
+// snapshot slot, so only there is T a per-chain variable (as a run-time choice it cost the chain-mode sweep 4 %: D = 340 56.7 -> 59.0 ms)
+template <int NT, bool NODE>
 __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, int rows)
 {
     const int n = p.n, ld = n + 1;
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
         // in, none out); its source is its parent's slot, or the fresh tableau.
         const double *src = p.T0;
         bool from_snap = false;
-        T = Tscratch;
-        if (p.node_code) {                                            // wave-uniform (kernel arguments and uniform loads)
+        if constexpr (NODE) T = Tscratch;
+        if constexpr (NODE) {                                         // wave-uniform (kernel arguments and uniform loads)
             if (p.node_dst && p.node_dst[chain]) T = p.node_dst[chain];
             if (p.node_src && p.node_src[chain]) { src = p.node_src[chain]; from_snap = true; }
         }
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                 p.node_sol[(size_t)chain * p.node_ld + i] = s_basic[i] ? qs[i] : 0.0;
             if (tid == 0) p.node_obj2[chain] = qs[n];
         }
-        if (p.node_code && T != Tscratch) {                          // the node leaves a snapshot: apply what is still pending, add q and the flags
+        if (NODE && T != Tscratch) {                                 // the node leaves a snapshot: apply what is still pending, add q and the flags
             if (Rcur > 0) {
                 if (tid < 4) dp[Rcur + tid] = 0.0;                    // padding of the last k-step
                 __syncthreads();
@@ -678,9 +680,15 @@ bool lazy_plan(int ld, int *mb_out, int *rows_out, size_t *shmem_out)
 template <int NT>
 static hipError_t launch_lazy_nt(const SweepParams &p, int grid, int mb, int rows, size_t shmem, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lazy_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sweep_lazy_kernel<NT>, dim3(grid), dim3(NT), shmem, s, p, mb, rows);
+    if (p.node_code) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lazy_kernel<NT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((sweep_lazy_kernel<NT, true>), dim3(grid), dim3(NT), shmem, s, p, mb, rows);
+    } else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lazy_kernel<NT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((sweep_lazy_kernel<NT, false>), dim3(grid), dim3(NT), shmem, s, p, mb, rows);
+    }
     return hipGetLastError();
 }
 
