@@ -246,3 +246,66 @@ def test_bnb_search_warm_protocol_single_and_gloo_world2(partls, oracle):
         assert (pat, free) == (cold[1], cold[2]) and abs(mu - cold[0]) <= 1e-12 * max(1.0, cold[0])
         assert live == 0 and warm > 0                                             # both ranks own snapshots and use them
     assert out[0][0][3] == out[1][0][3]
+
+
+class _FakeCtx:
+    """stands in for a Context in dist.reduce_winner: hands out a shard's candidates, records the merged list it is given and merges it
+    the way partls_opt_merge_candidates does (lexicographic minimum; near ties within `window` of the winner's objective^2)"""
+
+    def __init__(self, cands, window):
+        self.cands, self.window, self.merged = cands, window, None
+
+    def opt_candidates(self):
+        import numpy as np
+        return np.array([c[0] for c in self.cands]), np.array([c[1] for c in self.cands], dtype=np.int64)
+
+    def opt_merge_candidates(self, objs, pats):
+        allc = sorted({(float(o), int(p)) for o, p in zip(objs, pats) if p >= 0})
+        self.merged = allc
+        if not allc:
+            return float("inf"), -1
+        win = allc[0]
+        self.near = [p for o, p in allc[1:] if o * o <= win[0] ** 2 + self.window][:3]
+        return win
+
+
+def _winner_worker(rank, world, port, cases, out):
+    import torch.distributed as dist
+    import partls_amd
+    pls = partls_amd.package()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = []
+    for per_rank, window in cases:
+        ctx = _FakeCtx(per_rank[rank], window)
+        obj, pat = (per_rank[rank][0] if per_rank[rank] else (float("inf"), -1))
+        w = pls.dist.reduce_winner(ctx, obj, pat, order_key=3.0)
+        res.append((w, ctx.merged, getattr(ctx, "near", None)))
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_reduce_winner_gathers_every_shards_near_ties_gloo_world2(partls):
+    """dist.reduce_winner: one all-reduce(min) on the objective + one all-gather of every rank's winner and near ties.  Both ranks must end
+    with the SAME merged candidate list — the winner may sit on one rank and its near tie on the other — and hence install the same set."""
+    import torch.multiprocessing as mp
+    cases = [
+        ([[(2.0, 9), (2.0000001, 4)], [(2.00000005, 70)]], 1e-6),          # winner on rank 0, near ties on both ranks
+        ([[(3.0, 1)], [(1.0, 5), (1.0, 6)]], 1e-9),                        # winner and an exact tie on rank 1; rank 0 far away
+        ([[], [(4.0, 2)]], 1e-9),                                          # rank 0's shard was empty
+        ([[(1.5, 1 << 40)], [(1.5, (1 << 40) - 1)]], 0.0),                 # exact tie across ranks: first index; indices beyond 2^32
+    ]
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    procs = [ctx.Process(target=_winner_worker, args=(r, 2, port, cases, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r0, r1 = out[0], out[1]
+    assert [x[0] for x in r0] == [x[0] for x in r1] == [(2.0, 9), (1.0, 5), (4.0, 2), (1.5, (1 << 40) - 1)]
+    for a, b in zip(r0, r1):
+        assert a[1] == b[1] and a[2] == b[2]
+    assert r0[0][1] == [(2.0, 9), (2.00000005, 70), (2.0000001, 4)] and r0[0][2] == [70, 4]
+    assert r0[1][2] == [6] and r0[3][2] == [1 << 40]
