@@ -330,3 +330,43 @@ def test_alt_certificate_or_data_check(partls, oracle, monkeypatch):
         assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
         np.testing.assert_allclose(a, ref["alpha"], atol=1e-7)
     np.testing.assert_array_equal(res["certified"][0], res["checked"][0])
+
+
+@pytest.mark.parametrize("D,K,kind", [(170, 5, "plain"), (200, 4, "dup"), (240, 5, "null"), (257, 4, "triple"), (270, 5, "scaled"), (271, 3, "dup"), (288, 4, "plain")])
+def test_winner_from_the_512_thread_kernel_mid_sizes(partls, oracle, monkeypatch, D, K, kind):
+    """n = 171 .. 289 tableau variables run on the 512-thread register kernel, which since round 4 leaves the solution of its winner behind
+    (T <= 17 tile columns; 288 features: T = 18, the re-solve path): the finish starts from it — accepted only with the winning pattern's
+    signs, refined / verified in data space like a fresh solve.  Against the oracle and against the same fit with PARTLS_NO_EXPORT, with
+    duplicate, null, dependent and badly scaled columns and eta > 0."""
+    rng = np.random.default_rng(1000 + D)
+    N = 2 * D + 50
+    X = rng.standard_normal((N, D))
+    if kind == "dup":
+        X[:, 7] = X[:, 3]; X[:, D - 1] = X[:, D - 2]
+    elif kind == "null":
+        X[:, 5] = 0.0
+    elif kind == "triple":
+        X[:, 11] = 0.5 * X[:, 12] - 2.0 * X[:, 13]
+    elif kind == "scaled":
+        X *= np.exp(rng.uniform(-3, 3, size=D))[None, :]
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), rng.integers(0, K, size=D)] = 1
+    y = X @ (rng.random(D) * (rng.random(K) - 0.5)[P.argmax(1)] * 6) + 0.7 + 0.5 * rng.standard_normal(N)
+    eta = 0.3 if kind == "plain" else 0.0
+    ref = oracle.fit_opt(X, y, P, eta=eta)
+    res = {}
+    for mode in ("export", "resolve"):
+        if mode == "resolve":
+            monkeypatch.setenv("PARTLS_NO_EXPORT", "1")
+        ctx = partls.Context(0)
+        try:
+            ctx.opt_prepare(X, y, P, eta, 0)
+            bo, bp, _, unconv = ctx.opt_sweep(0, -1)
+            assert unconv == 0
+            res[mode] = ctx.opt_finish(bp)
+        finally:
+            ctx.close()
+    for mode, (a, b, t, opt, bi) in res.items():
+        assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]), mode
+        np.testing.assert_allclose(partls.predict(partls.PartLSFitResult(a, b, t, P), X), oracle.predict(X, P, ref["alpha"], ref["beta"], ref["t"]),
+                                   atol=1e-6 * np.linalg.norm(y), err_msg=mode)
+    assert res["export"][4] == res["resolve"][4] and abs(res["export"][3] - res["resolve"][3]) <= 1e-12 * res["resolve"][3]
