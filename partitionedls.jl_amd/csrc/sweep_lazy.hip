@@ -28,6 +28,9 @@ static constexpr int LZ_MAXR = 64;          // rows of the LDS pool at most
 #ifndef LZ_TWO_PHASE_MAX_NT
 #define LZ_TWO_PHASE_MAX_NT 1024           // workgroup sizes up to this run the two-phase panel (512: the 1024-thread plan keeps the step-by-step one)
 #endif
+#ifndef LZ_PANEL_STEPS
+#define LZ_PANEL_STEPS 1                    // 1: the 512-thread plan runs the block panel in the register kernel's one-barrier-per-step form (lz_panel_steps); 0: two-phase everywhere (round 3)
+#endif
 #ifndef LZ_MIN_SPLIT
 #define LZ_MIN_SPLIT 6                      // a block is cut short to fill the pool when at least this many pivots still fit
 #endif
@@ -318,6 +321,106 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
 
 // NODE: node mode (BnB bounds, Alt alpha-steps, calibration walks) is its own instantiation: only there can the base image live in a
 // snapshot slot, so only there is T a per-chain variable (as a run-time choice it cost the chain-mode sweep 4 %: D = 340 56.7 -> 59.0 ms)
+// ---- the panel in the register kernel's form (round 4; LZ_PANEL_STEPS) ------------------------------------------------------------------
+// sweep_blk.hip's panel_block: thread t owns ROW t of the block's M (compile-time) pivot columns in registers; M Gauss–Jordan steps, ONE
+// barrier each: the pivot-row threads publish their entry of the current pivot column (U, double buffered by step parity), the one
+// pivot-row thread of the step computes 1/d, everybody reads both back and updates its own row — straight-line code per M, no guards.
+// 585 cycles per step in tools/ubench/panel_two_phase.hip against the ~1.8k per pivot the two-phase form above costs HERE (its phase 1
+// needs two wave permutes per step to serve up to 16 columns from 4 per lane).  Same operations in the same order on every row as
+// lz_panel_eliminate / gj_panel_eliminate; the leave-one-out veto is raised per row and step and resolved by the caller (redo from the
+// untouched panel image with the offender skipped).  U: [2][16 + 64] doubles (slots 16.. are per-lane dummies).
+template <int M>
+__device__ __forceinline__ int lz_panel_steps(const double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ U, double *__restrict__ dn,
+                                              int ld, int myj, bool my_basic, unsigned skip, double piv_eps, int tid, bool has_row, bool var_row,
+                                              bool idle_wave, double (&pv)[GJ_MB])
+{
+    if (idle_wave) {
+#pragma unroll
+        for (int s = 0; s < M; ++s) __syncthreads();
+        return M;
+    }
+    constexpr int US = GJ_MB + 64;
+    const int row = has_row ? tid : ld - 1;                  // threads beyond the rhs row shadow it: computed, never stored
+    const int uslot = myj >= 0 ? myj : GJ_MB + (tid & 63);
+#pragma unroll
+    for (int j = 0; j < M; ++j) pv[j] = Pn[(size_t)j * ld + row];
+    int veto = M;
+#pragma unroll
+    for (int s = 0; s < M; ++s) {
+        if (has_row) Zn[(size_t)s * ld + tid] = pv[s];
+        U[(s & 1) * US + uslot] = pv[s];
+        if (myj == s) {                                      // the one pivot-row thread (its wave only: the others branch over)
+            const double d = pv[s];
+            dn[s] = (!((skip >> s) & 1u) && (my_basic || d > piv_eps)) ? gj_rcp(d) : 0.0;
+        }
+        __syncthreads();
+        double inv = dn[s];
+        double u[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
+        asm volatile("" : "+v"(inv));
+#pragma unroll
+        for (int j = 0; j < M; ++j) asm volatile("" : "+v"(u[j]));
+        // leave-one-out veto: T_js^2 >= d / piv_eps  (inv = 1/d; negative for a leaving pivot, 0 for a rejected one); the rhs row is no variable
+        if (var_row && (pv[s] * pv[s]) * (inv * piv_eps) >= 1.0) veto = veto < s ? veto : s;
+        if (__builtin_amdgcn_readfirstlane(__double2hiint(inv)) & 0x7ff00000) {
+            const double ainv = fabs(inv), fz = -pv[s] * inv;
+            if (myj == s) {
+#pragma unroll
+                for (int j = 0; j < M; ++j) pv[j] = (j == s) ? -inv : u[j] * ainv;
+            } else {
+#pragma unroll
+                for (int j = 0; j < M; ++j) pv[j] = (j == s) ? pv[s] * ainv : fma(fz, u[j], pv[j]);
+            }
+        }
+    }
+    return veto;
+}
+
+// the block's panel through lz_panel_steps: redo on a veto, write the final panel back, flip the basis flags of the accepted pivots;
+// returns the number of accepted pivots
+template <int NT>
+__device__ __forceinline__ int lz_panel_stepwise(double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ dn, double *__restrict__ U,
+                                                 int *__restrict__ vflag, int m_, int ld_, uint8_t *__restrict__ s_basic, int myj, double piv_eps,
+                                                 int tid, unsigned long long &nveto)
+{
+    const int m = __builtin_amdgcn_readfirstlane(m_), ld = __builtin_amdgcn_readfirstlane(ld_);
+    const bool has_row = tid < ld, var_row = tid < ld - 1;
+    const bool idle_wave = __builtin_amdgcn_readfirstlane((tid & ~63) >= ld ? 1 : 0) != 0;
+    const bool my_basic = myj >= 0 && s_basic[tid] != 0;
+    const int lane = tid & 63;
+    unsigned skip = 0;
+    double pv[GJ_MB];
+    for (;;) {
+        if (tid == 0) *vflag = GJ_MB;
+        // (the barrier of the first step orders this store before every atomicMin below: a veto is only raised after step 0's barrier)
+        int veto;
+        switch (m) {
+#define LZ_PS(i) case i: veto = lz_panel_steps<i>(Pn, Zn, U, dn, ld, myj, my_basic, skip, piv_eps, tid, has_row, var_row, idle_wave, pv); break;
+            LZ_PS(1) LZ_PS(2) LZ_PS(3) LZ_PS(4) LZ_PS(5) LZ_PS(6) LZ_PS(7) LZ_PS(8) LZ_PS(9) LZ_PS(10) LZ_PS(11) LZ_PS(12) LZ_PS(13) LZ_PS(14) LZ_PS(15)
+#undef LZ_PS
+            default: veto = lz_panel_steps<GJ_MB>(Pn, Zn, U, dn, ld, myj, my_basic, skip, piv_eps, tid, has_row, var_row, idle_wave, pv); break;
+        }
+        if (veto < m) atomicMin(vflag, veto);
+        __syncthreads();
+        const int vs = __builtin_amdgcn_readfirstlane(*vflag);
+        if (vs >= m) break;
+        skip |= 1u << vs;                                     // the first refused step changes every later one: one at a time
+        ++nveto;
+        __syncthreads();                                      // everybody has read the flag before thread 0 resets it
+    }
+    // the final panel: rows / columns of the pivoted variables (the panel image was not touched until here)
+    if (has_row && !idle_wave) {
+#pragma unroll
+        for (int j = 0; j < GJ_MB; ++j) if (j < m) Pn[(size_t)j * ld + tid] = pv[j];
+    }
+    const double dmy = dn[lane < m ? lane : 0];
+    const unsigned accm = (unsigned)__ballot(lane < m && dmy != 0.0);
+    if (myj >= 0 && dn[myj] != 0.0) s_basic[tid] ^= 1;         // accepted pivots change sides
+    __syncthreads();
+    return __popc(accm);
+}
+
 template <int NT, bool NODE>
 __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, int rows)
 {
@@ -524,7 +627,13 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                     LZ_STAMP(3);                                              // gather + materialise
                     double *Zn = Zp + (size_t)Rcur * ld, *dn = dp + Rcur;
                     int acc_piv;
-                    if constexpr (NT <= 512) {
+                    if constexpr (LZ_PANEL_STEPS && NT <= 512) {
+                        // one barrier per step, the register kernel's panel: 2-4 % ahead of the two-phase form on the 512-thread plan (D = 340:
+                        // 4.64 -> 4.74 M solves/s, D = 500: 608 -> 634 k), and no polled progress word; on the 1024-thread plan a barrier
+                        // meets 16 waves and the form is 2x slower (D = 600: 12.5 -> 26.9 ms per 4096 patterns): there the two-phase form stays
+                        acc_piv = lz_panel_stepwise<NT>(Pn, Zn, dn, tab, reinterpret_cast<int *>(red), m, ld, s_basic, myj, p.piv_eps, tid, nveto);
+                        (void)lz_fault; (void)basm;
+                    } else if constexpr (NT <= 512) {
                         acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK, lz_fault)
                                          : lz_panel_eliminate<NT, GJ_MB>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK, lz_fault);
                         lz_fault = false;

@@ -183,11 +183,12 @@ def test_bnb_warm_starts_beyond_320_equal_cold_ones(partls, oracle, monkeypatch,
 
 
 def test_a_lost_progress_word_ends_in_not_converged_not_in_a_hang(partls, monkeypatch):
-    """The two-phase panel's followers wait for the progress word of the wave that runs phase 1 — a bounded wait (2^22 polls).  Fault
+    """The two-phase panel (n >= 512 since round 4; below, the panel takes one barrier per step and polls nothing): its followers wait for
+    the progress word of the wave that runs phase 1 — a bounded wait (2^22 polls).  Fault
     injection (PARTLS_LZ_FAULT): workgroup 0's first panel never publishes the word.  The kernel must finish (every wave reaches the bound
     and walks on), and the sweep must not pass the garbage off as a result: the unconverged count is raised, fit() raises status 6."""
     import time
-    X, y, P = _problem(31, 600, 330, 3)
+    X, y, P = _problem(31, 900, 520, 3)                              # n >= 512: the 1024-thread plan, where the two-phase panel runs
     monkeypatch.setenv("PARTLS_LZ_FAULT", "1")
     ctx = partls.Context(0)
     try:
