@@ -518,6 +518,105 @@ double kkt_violation_data(const partls_ctx *c, const std::vector<double> &w, con
     return worstv;
 }
 
+// Row-oriented Cholesky of a dense SPD matrix, in place (lower triangle, row-major, leading dimension p): L[i][j] = (B[i][j] - <L[i][:j],
+// L[j][:j]>) / L[j][j].  The inner products run on 2 x 4 AVX2 lanes where the host has them (every host an MI355X ships in; checked at
+// run time) — 358 k multiply-adds at p = 129 in ~25 us instead of ~100: short enough to hide behind the first data pass of the refinement.
+// The sums are taken in a fixed order per build target (reproducible run to run; the correction they serve is ~1e-15 of the solution).
+#if defined(__x86_64__)
+#include <immintrin.h>
+// 4 rows x 2 columns at a time: L[i][j] for i = i0..i0+3 and j = j0, j0+1 share the six row loads of a k-step (0.75 loads per FMA instead of
+// 2: the plain dot-product form streams the whole factor from L2 once per row — 45 MB at p = 256, which is what bounded it at ~5 GFLOP/s).
+__attribute__((target("avx2,fma"))) static inline double hsum4(__m256d v)
+{
+    double t[4];
+    _mm256_storeu_pd(t, v);
+    return (t[0] + t[1]) + (t[2] + t[3]);
+}
+__attribute__((target("avx2,fma"))) static bool chol_rows_avx2(double *L, int p)
+{
+    int i0 = 0;
+    for (; i0 + 3 < p; i0 += 4) {
+        double *R0 = L + (size_t)i0 * p, *R1 = R0 + p, *R2 = R1 + p, *R3 = R2 + p;
+        // columns strictly before the diagonal block, two at a time
+        int j = 0;
+        for (; j + 1 < i0; j += 2) {
+            const double *C0 = L + (size_t)j * p, *C1 = C0 + p;
+            __m256d a00 = _mm256_setzero_pd(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00, a30 = a00, a31 = a00;
+            int k = 0;
+            for (; k + 3 < j; k += 4) {
+                const __m256d c0 = _mm256_loadu_pd(C0 + k), c1 = _mm256_loadu_pd(C1 + k);
+                const __m256d r0 = _mm256_loadu_pd(R0 + k), r1 = _mm256_loadu_pd(R1 + k), r2 = _mm256_loadu_pd(R2 + k), r3 = _mm256_loadu_pd(R3 + k);
+                a00 = _mm256_fmadd_pd(r0, c0, a00); a01 = _mm256_fmadd_pd(r0, c1, a01);
+                a10 = _mm256_fmadd_pd(r1, c0, a10); a11 = _mm256_fmadd_pd(r1, c1, a11);
+                a20 = _mm256_fmadd_pd(r2, c0, a20); a21 = _mm256_fmadd_pd(r2, c1, a21);
+                a30 = _mm256_fmadd_pd(r3, c0, a30); a31 = _mm256_fmadd_pd(r3, c1, a31);
+            }
+            double d[4][2] = {{hsum4(a00), hsum4(a01)}, {hsum4(a10), hsum4(a11)}, {hsum4(a20), hsum4(a21)}, {hsum4(a30), hsum4(a31)}};
+            double *R[4] = {R0, R1, R2, R3};
+            for (int a = 0; a < 4; ++a) {
+                for (int kk = k; kk < j; ++kk) { d[a][0] += R[a][kk] * C0[kk]; d[a][1] += R[a][kk] * C1[kk]; }
+                const double l0 = (R[a][j] - d[a][0]) / C0[j];
+                R[a][j] = l0;
+                R[a][j + 1] = (R[a][j + 1] - (d[a][1] + l0 * C1[j])) / C1[j + 1];       // column j + 1 also needs the entry of column j just made
+            }
+        }
+        // the odd column before the block, then the 4 x 4 diagonal block: plain
+        for (int a = 0; a < 4; ++a) {
+            double *Ri = L + (size_t)(i0 + a) * p;
+            for (int jj = j; jj <= i0 + a; ++jj) {
+                const double *Cj = L + (size_t)jj * p;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int k = 0;
+                for (; k + 3 < jj; k += 4) { s0 += Ri[k] * Cj[k]; s1 += Ri[k + 1] * Cj[k + 1]; s2 += Ri[k + 2] * Cj[k + 2]; s3 += Ri[k + 3] * Cj[k + 3]; }
+                for (; k < jj; ++k) s0 += Ri[k] * Cj[k];
+                const double sv = Ri[jj] - ((s0 + s1) + (s2 + s3));
+                if (jj == i0 + a) { if (!(sv > 0.0)) return false; Ri[jj] = std::sqrt(sv); }
+                else Ri[jj] = sv / Cj[jj];
+            }
+        }
+    }
+    for (int i = i0; i < p; ++i) {                           // the last p mod 4 rows
+        double *Li = L + (size_t)i * p;
+        for (int j = 0; j <= i; ++j) {
+            const double *Lj = L + (size_t)j * p;
+            double s0 = 0.0, s1 = 0.0;
+            int k = 0;
+            for (; k + 1 < j; k += 2) { s0 += Li[k] * Lj[k]; s1 += Li[k + 1] * Lj[k + 1]; }
+            for (; k < j; ++k) s0 += Li[k] * Lj[k];
+            const double sv = Li[j] - (s0 + s1);
+            if (i == j) { if (!(sv > 0.0)) return false; Li[i] = std::sqrt(sv); }
+            else Li[j] = sv / Lj[j];
+        }
+    }
+    return true;
+}
+#endif
+static bool chol_rows_plain(double *L, int p)
+{
+    for (int i = 0; i < p; ++i) {
+        double *Li = L + (size_t)i * p;
+        for (int j = 0; j <= i; ++j) {
+            const double *Lj = L + (size_t)j * p;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = 0;
+            for (; k + 3 < j; k += 4) { s0 += Li[k] * Lj[k]; s1 += Li[k + 1] * Lj[k + 1]; s2 += Li[k + 2] * Lj[k + 2]; s3 += Li[k + 3] * Lj[k + 3]; }
+            for (; k < j; ++k) s0 += Li[k] * Lj[k];
+            const double s = Li[j] - ((s0 + s1) + (s2 + s3));
+            if (i == j) { if (!(s > 0.0)) return false; Li[i] = std::sqrt(s); }
+            else Li[j] = s / Lj[j];
+        }
+    }
+    return true;
+}
+static bool chol_rows(double *L, int p)
+{
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+    if (fast) return chol_rows_avx2(L, p);
+#endif
+    return chol_rows_plain(L, p);
+}
+
 partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_intercept, int steps, RefineOut *out)
 {
     const int64_t M = c->M;
@@ -576,7 +675,13 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
         for (int64_t j = 0; j <= M; ++j) {
             const double dj = delta[(size_t)j];
             if (dj == 0.0) continue;
-            for (int64_t m = 0; m <= M; ++m) out->g[(size_t)m] -= h_reg(c, (int)m, (int)j) * dj;
+            const double *row = c->hG.data() + (size_t)j * c->ldg;          // row j of the symmetric Gram copy: contiguous
+            double *og = out->g.data();
+            for (int64_t m = 0; m <= M; ++m) og[m] -= row[m] * dj;
+            if (c->eta != 0.0) {
+                const uint64_t mj = c->mask_aug[(size_t)j];
+                for (int64_t m = 0; m <= M; ++m) og[m] -= c->eta * (double)__builtin_popcountll(c->mask_aug[(size_t)m] & mj) * dj;
+            }
         }
         out->obj = std::sqrt(o2 > 0.0 ? o2 : 0.0);
         out->have = true;
@@ -587,51 +692,32 @@ partls_status refine_solution(partls_ctx *c, std::vector<double> &w, bool free_i
     // p^3 / 6 multiply-adds).  It runs while the device computes the first residual and gradient.
     auto factorise = [&]() -> bool {
         Lc.assign((size_t)p * p, 0.0);
-        auto dot4 = [](const double *__restrict a, const double *__restrict b, int nk) {
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = 0;
-            for (; k + 3 < nk; k += 4) { s0 += a[k] * b[k]; s1 += a[k + 1] * b[k + 1]; s2 += a[k + 2] * b[k + 2]; s3 += a[k + 3] * b[k + 3]; }
-            for (; k < nk; ++k) s0 += a[k] * b[k];
-            return (s0 + s1) + (s2 + s3);
-        };
-        for (int i = 0; i < p; ++i) {
+        for (int i = 0; i < p; ++i) {                        // the regularised Gram block of the support, lower triangle
+            const double *row = c->hG.data() + (size_t)sup[(size_t)i] * c->ldg;
             double *Li = &Lc[(size_t)i * p];
-            for (int j = 0; j <= i; ++j) {
-                const double *Lj = &Lc[(size_t)j * p];
-                const double s = h_reg(c, sup[(size_t)i], sup[(size_t)j]) - dot4(Li, Lj, j);
-                if (i == j) { if (!(s > 0.0)) return false; Li[i] = std::sqrt(s); }
-                else Li[j] = s / Lj[j];
+            for (int j = 0; j <= i; ++j) Li[j] = row[sup[(size_t)j]];
+            if (c->eta != 0.0) {
+                const uint64_t mi = c->mask_aug[(size_t)sup[(size_t)i]];
+                for (int j = 0; j <= i; ++j) Li[j] += c->eta * (double)__builtin_popcountll(mi & c->mask_aug[(size_t)sup[(size_t)j]]);
             }
         }
-        return true;
+        return chol_rows(Lc.data(), p);
     };
     const auto r0 = std::chrono::steady_clock::now();
     for (int it = 0; it < steps; ++it) {
         bool spd = true;
         // residual (and squared residual) and gradient on the device(s); the Cholesky factorisation, when it is needed, overlaps with them
-        partls_status dst = data_pass(c, w, out != nullptr, true, &obj2_pre, &g, {});
+        // (round 4 tried to skip the factorisation when the data-space gradient on the support is rounding noise already — C2: 2.6e-16 of
+        // ||x|| ||y|| — and took it back: a tiny gradient says nothing about the error along a weak direction of the Gram block (error =
+        // gradient / lambda_min: at cond(Xo) = 8e4 a gradient of 1e-16 goes with an error of 1e-7, exactly the case the refinement exists
+        // for; found by test_ill_conditioned_model_parity under a forced bit-order calibration).  The factorisation is made cheap instead.)
+        partls_status dst = data_pass(c, w, out != nullptr, true, &obj2_pre, &g, [&]() { if (it == 0 && !use_tab) spd = factorise(); });
         if (dst != PARTLS_OK) return dst;
         if (out) {
             eta_terms(c, w, &obj2_pre, nullptr);
             std::fill(delta.begin(), delta.end(), 0.0);
         }
         eta_terms(c, w, nullptr, &g);                        // gradient of the η rows: -eta * sum_k 1_k (1_k' w)
-        if (!use_tab && it == 0) {
-            // Is there anything to correct?  On data the Gram form resolves, the data-space gradient on the support is rounding noise already
-            // (C2: 2.6e-16 of ||x|| ||y||, the correction 6e-16 of |w|): then the p^3 / 6 factorisation — 0.1 ms at p = 129, half of the
-            // whole finish of a C2-sized fit — buys nothing.  Below 1e-14 the solution's error along the weakest direction is below
-            // cond * 1e-14 (cond <= ~100 for the gradient to be that small at all): the pass's objective and gradient ARE the result.
-            const double yy = h_reg(c, (int)M + 1, (int)M + 1);
-            double gmax = 0.0;
-            for (int i = 0; i < p; ++i) {
-                const int m = sup[(size_t)i];
-                const double dd = h_reg(c, m, m);
-                gmax = std::max(gmax, (dd > 0.0 && yy > 0.0) ? std::fabs(g[(size_t)m]) / std::sqrt(dd * yy) : (g[(size_t)m] != 0.0 ? 1.0 : 0.0));
-            }
-            if (c->knobs.finish_trace) fprintf(stderr, "[refine] max |g_S| / (|x||y|) of the Gram-form solution = %.3e%s\n", gmax, gmax <= 1e-14 ? ": nothing to correct" : "");
-            if (gmax <= 1e-14) { if (out) finish_out(); break; }
-            spd = factorise();
-        }
         if (!spd) return PARTLS_OK;                          // not numerically SPD: give up quietly, w unchanged
         if (use_tab) {
             const int nb = (int)tabsup.size();
