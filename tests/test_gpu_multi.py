@@ -388,3 +388,25 @@ def test_views_of_a_closed_multi_context_do_not_dangle(partls, oracle):
         view._shape = (X.shape[0], X.shape[1], P.shape[1])
         o, model = sols[int(bi)]                                             # rebuilt on a private context, not through the dead view
         assert abs(o - opt) <= 1e-9 * max(1.0, opt)
+
+
+def test_row_blocks_go_up_through_the_staged_upload(partls, oracle):
+    """Row blocks above 8 MB are staged through page-locked buffers by copier threads INSIDE every rank thread (a strided view of the
+    caller's matrix per rank): same fit as the single context, whose own upload is staged too."""
+    rng = np.random.default_rng(3)
+    N, D, K = 300_000, 8, 3
+    X = np.asfortranarray(rng.standard_normal((N, D)))
+    P = np.zeros((D, K), dtype=np.int64); P[np.arange(D), np.arange(D) % K] = 1
+    y = X @ (rng.random(D) * np.array([1.0, -2.0, 0.5])[np.arange(D) % K]) + 0.2 + 0.3 * rng.standard_normal(N)
+    a1, b1, t1, opt1, bi1, _ = _single(partls, X, y, P)
+    assert partls.default_context().upload()[1] == N * D * 8
+    mc = partls.MultiContext([0, 0])
+    try:
+        a, b, t, opt, bi, _ = mc.fit_opt(X, y, P)
+        assert mc.context(0).upload()[1] == (N // 2) * D * 8 and mc.context(1).upload()[1] == (N - N // 2) * D * 8
+        assert bi == bi1 and abs(opt - opt1) <= 1e-11 * opt1
+        np.testing.assert_allclose(a, a1, atol=1e-10)
+        a, b, t, opt, nopen = mc.fit_bnb(X, y, P)
+        assert abs(opt - opt1) <= 1e-9 * opt1
+    finally:
+        mc.close()
