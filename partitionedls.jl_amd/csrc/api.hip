@@ -228,7 +228,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     }
     t_end(c, PARTLS_T_PREP);
     PARTLS_HIP_CHECK(c->hG.resize((size_t)c->ldg * c->ldg));
-    c->hScale.resize((size_t)c->n);
+    PARTLS_HIP_CHECK(c->hScale.resize((size_t)c->n));
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->hG.data(), c->G.p, c->hG.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipMemcpyAsync(c->hScale.data(), c->scale.p, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -359,8 +359,9 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
     }
     unsigned long long counters[4] = {0, 0, 0, 0};                 // unconverged, pivots, vetoes, (cooperative kernel) blocks
-    std::vector<double> outw(out_words);
-    PARTLS_HIP_CHECK(hipMemcpyAsync(outw.data(), c->nodeSol.p, out_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(c->nodeOut.resize(out_words));
+    const double *outw = c->nodeOut.data();
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeOut.data(), c->nodeSol.p, out_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (dump_reg) {
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->nodeTab.p, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hBasic, c->nodeBasic.p, (size_t)16 * c->T, hipMemcpyDeviceToHost, c->stream));
@@ -373,7 +374,7 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->scratch.as<double>() + img, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
-    std::memcpy(counters, outw.data(), sizeof(counters));
+    std::memcpy(counters, outw, sizeof(counters));
     if (coop && (counters[0] >> 40)) {
         // grid-barrier timeout: some workgroups of the cooperative grid were not resident (the device is shared with another
         // context or process).  Nothing of that attempt is used; the same node is solved again by ONE workgroup, which needs no
@@ -382,8 +383,8 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         return solve_nodes(c, codes, cnt, sols, obj2, unconv, false, want_tab);
     }
     if (coop) c->coop_state_valid = counters[0] == 0;
-    std::copy(outw.begin() + 4, outw.begin() + 4 + (ptrdiff_t)cnt, obj2.begin());
-    std::copy(outw.begin() + 4 + (ptrdiff_t)cnt, outw.end(), sols.begin());
+    std::copy(outw + 4, outw + 4 + cnt, obj2.begin());
+    std::copy(outw + 4 + cnt, outw + out_words, sols.begin());
     if (unconv) *unconv = counters[0];
     c->last_pivots = counters[1]; c->last_vetoes = counters[2]; c->last_blocks = counters[3];
     c->tab_valid = dump && counters[0] == 0;
@@ -423,12 +424,12 @@ partls_status data_pass(partls_ctx *c, const std::vector<double> &w, bool want_o
         PARTLS_HIP_CHECK(q->wdev.ensure((size_t)(M + 1) * sizeof(double)));
         PARTLS_HIP_CHECK(hipMemcpyAsync(q->wdev.p, w.data(), (size_t)(M + 1) * sizeof(double), hipMemcpyHostToDevice, q->stream));
         double *yhat = nullptr;
-        if (want_obj) { PARTLS_HIP_CHECK(q->partial.ensure(nb * sizeof(double))); q->hPart.resize((size_t)nb); }
+        if (want_obj) { PARTLS_HIP_CHECK(q->partial.ensure(nb * sizeof(double))); PARTLS_HIP_CHECK(q->hPart.resize((size_t)nb)); }
         if (want_grad) {
             PARTLS_HIP_CHECK(q->yhatD.ensure((size_t)N * sizeof(double)));
             PARTLS_HIP_CHECK(q->gD.ensure((size_t)xr * (M + 1) * sizeof(double)));
             yhat = q->yhatD.as<double>();
-            q->hGpart.resize((size_t)xr * (M + 1));
+            PARTLS_HIP_CHECK(q->hGpart.resize((size_t)xr * (M + 1)));
         }
         PARTLS_HIP_CHECK(launch_residual(q->dX, N, M, q->ldX, want_obj ? q->dy : nullptr, q->wdev.as<double>(), w[(size_t)M],
                                          want_obj ? q->partial.as<double>() : nullptr, nb, yhat, q->stream));
@@ -920,6 +921,7 @@ void partls_destroy(partls_ctx *c)
         c->bnbChunks.clear();
         c->hG.release();
         c->bnbHostIn.release(); c->bnbHostOut.release();
+        c->hScale.release(); c->hPart.release(); c->hGpart.release(); c->sweepOut.release(); c->nodeOut.release(); c->exportSol.release();
         for (int i = 0; i < 8; ++i) { if (c->upPin[i]) (void)hipHostFree(c->upPin[i]); if (c->upEvent[i]) (void)hipEventDestroy(c->upEvent[i]); }
         for (int t = 0; t < 4; ++t) if (c->upStream[t]) (void)hipStreamDestroy(c->upStream[t]);
         if (c->hTab) (void)hipHostFree(c->hTab);
@@ -1161,8 +1163,9 @@ try {
     std::vector<double> bo((size_t)grid);
     std::vector<int64_t> bp((size_t)grid);
     unsigned long long cnt[3] = {0, 0, 0};
-    std::vector<double> sweep_out(sweep_words);
-    PARTLS_HIP_CHECK(hipMemcpyAsync(sweep_out.data(), c->bestObj.p, sweep_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PARTLS_HIP_CHECK(c->sweepOut.resize(sweep_words));
+    const double *sweep_out = c->sweepOut.data();
+    PARTLS_HIP_CHECK(hipMemcpyAsync(c->sweepOut.data(), c->bestObj.p, sweep_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (all_opt) {
         // only the entries of this shard are set, the others are NaN; the caller merges shards (entries are indexed by pattern)
         const void *src = c->allOpt.p;
@@ -1175,9 +1178,9 @@ try {
     }
     PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
     t_collect(c);
-    std::memcpy(cnt, sweep_out.data(), sizeof(cnt));
-    std::memcpy(bo.data(), sweep_out.data() + 4, (size_t)grid * sizeof(double));
-    std::memcpy(bp.data(), sweep_out.data() + 4 + grid, (size_t)grid * sizeof(int64_t));
+    std::memcpy(cnt, sweep_out, sizeof(cnt));
+    std::memcpy(bo.data(), sweep_out + 4, (size_t)grid * sizeof(double));
+    std::memcpy(bp.data(), sweep_out + 4 + grid, (size_t)grid * sizeof(int64_t));
     c->last_pivots = cnt[1];
     c->last_vetoes = cnt[2];
     c->sweep_vetoes = cnt[2];
@@ -1210,8 +1213,8 @@ try {
         const double yy = h_reg(c, (int)c->M + 1, (int)c->M + 1);
         const double lim2 = bobj * bobj + c->knobs.near_tie_rel * (yy > 0.0 ? yy : 0.0);
         std::vector<std::pair<double, int64_t>> cand;
-        const double *so = sweep_out.data() + 4 + 2 * (size_t)grid;
-        const int64_t *sp = reinterpret_cast<const int64_t *>(sweep_out.data() + 4 + 3 * (size_t)grid);
+        const double *so = sweep_out + 4 + 2 * (size_t)grid;
+        const int64_t *sp = reinterpret_cast<const int64_t *>(sweep_out + 4 + 3 * (size_t)grid);
         for (int i = 0; i < grid; ++i) {
             if (bp[(size_t)i] >= 0 && bp[(size_t)i] != bpat && bo[(size_t)i] * bo[(size_t)i] <= lim2) cand.emplace_back(bo[(size_t)i], bp[(size_t)i]);
             if (sp[i] >= 0 && so[i] * so[i] <= lim2) { const int64_t r = reference_pattern(c, sp[i]); if (r != bpat) cand.emplace_back(so[i], r); }
@@ -1271,9 +1274,10 @@ try {
             // the winner's solution as the sweep left it (scaled, 0 for nonbasic variables — the format of a node solve); accepted when
             // it carries the winning pattern's signs (on an exact objective tie the kernel keeps the FIRST pattern's solution, which
             // may belong to the other pattern of the tie), refined and KKT-checked below like any other
-            sols.assign((size_t)c->n, 0.0);
-            PARTLS_HIP_CHECK(hipMemcpyAsync(sols.data(), c->bestSol.as<double>() + (size_t)export_wg * c->n, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            PARTLS_HIP_CHECK(c->exportSol.resize((size_t)c->n));
+            PARTLS_HIP_CHECK(hipMemcpyAsync(c->exportSol.data(), c->bestSol.as<double>() + (size_t)export_wg * c->n, (size_t)c->n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             PARTLS_HIP_CHECK(hipStreamSynchronize(c->stream));
+            sols.assign(c->exportSol.data(), c->exportSol.data() + c->n);
             opt_codes(c, cands[ci], codes);
             taken = true;
             double smax = 0.0;

@@ -115,7 +115,9 @@ struct partls_ctx {
     // rows of X sharded over several devices (partls_fit_opt_multi): the contexts that hold the OTHER row blocks of the problem this
     // context is prepared for; every pass over the data (data_pass, api.hip) then covers them too.  Cleared by every prepare.
     std::vector<partls_ctx *> peers;
-    std::vector<double> hPart, hGpart;             // host staging of a data pass
+    partls::PinnedDoubles hPart, hGpart;           // host staging of a data pass (page-locked like every device -> host destination of a fit: a pageable
+                                                   // one costs 17-30 us of runtime staging per copy and blocks the caller — a third of a C2-sized fit's host time)
+    partls::PinnedDoubles sweepOut, nodeOut, exportSol;   // ... of a sweep's per-workgroup results, of a node batch, of the sweep's solution of its winner
     // called between the Gram build and the tableau preparation (partls_fit_opt_multi: the Gram products of the row blocks are summed)
     std::function<partls_status(partls_ctx *)> gram_hook;
     partls::PinnedDoubles bnbHostIn, bnbHostOut;   // page-locked staging of a node batch (8-byte words): the two copies of a round cost ~10 us each instead of ~25 pageable
@@ -126,7 +128,7 @@ struct partls_ctx {
     hipEvent_t upEvent[8] = {};
     double last_upload_ms = 0.0, last_upload_bytes = 0.0;
     partls::PinnedDoubles hG;                      // host copy of the augmented Gram (pinned: 0.8 MB per prepare at C3)
-    std::vector<double> hScale;
+    partls::PinnedDoubles hScale;
     // tableau: variable i of the tableau is augmented-Gram index perm[i] (features grouped by partition)
     int n = 0, kbits = 0, T = 0;
     std::vector<int> perm;
