@@ -330,21 +330,31 @@ __device__ __forceinline__ int lz_panel_eliminate(double *__restrict__ Pn, doubl
 // lz_panel_eliminate / gj_panel_eliminate; the leave-one-out veto is raised per row and step and resolved by the caller (redo from the
 // untouched panel image with the offender skipped).  U: [2][16 + 64] doubles (slots 16.. are per-lane dummies).
 template <int M>
-__device__ __forceinline__ int lz_panel_steps(const double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ U, double *__restrict__ dn,
-                                              int ld, int myj, bool my_basic, unsigned skip, double piv_eps, int tid, bool has_row, bool var_row,
-                                              bool idle_wave, double (&pv)[GJ_MB])
+__device__ __forceinline__ int lz_panel_steps(double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ U, double *__restrict__ dn,
+                                              int *__restrict__ vflag, int ld, int myj, bool my_basic, unsigned skip, double piv_eps, int tid,
+                                              bool has_row, bool var_row, bool idle_wave, unsigned long long *stk = nullptr)
 {
+#ifdef PARTLS_LZ_STAMPS
+    unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
     if (idle_wave) {
 #pragma unroll
         for (int s = 0; s < M; ++s) __syncthreads();
-        return M;
+        __syncthreads();                                     // the veto word's barrier
+        return __builtin_amdgcn_readfirstlane(*vflag);
     }
     constexpr int US = GJ_MB + 64;
     const int row = has_row ? tid : ld - 1;                  // threads beyond the rhs row shadow it: computed, never stored
     const int uslot = myj >= 0 ? myj : GJ_MB + (tid & 63);
+    // The row lives in an array of exactly M doubles that never leaves this function (round 4: as a 16-wide array handed back to the caller
+    // of the switch over M, every join of the per-lane `pivot row?` branch below copied all 16 registers — 30-40 v_mov_b64 per step, 1.5k
+    // cycles per step against the 585 of tools/ubench/panel_two_phase.hip), and the row update is ONE instruction stream for pivot and
+    // other rows (multiplier and addend selected per lane, as phase 1 of lz_panel_eliminate does).
+    double pv[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) pv[j] = Pn[(size_t)j * ld + row];
     int veto = M;
+    LZ_PSTAMP(8);
 #pragma unroll
     for (int s = 0; s < M; ++s) {
         if (has_row) Zn[(size_t)s * ld + tid] = pv[s];
@@ -354,70 +364,80 @@ __device__ __forceinline__ int lz_panel_steps(const double *__restrict__ Pn, dou
             dn[s] = (!((skip >> s) & 1u) && (my_basic || d > piv_eps)) ? gj_rcp(d) : 0.0;
         }
         __syncthreads();
+        // ONE LDS read brings the pivot rows' entries of column s into every wave: lane l of every row of 16 lanes holds u_l, and the row
+        // update takes u_j from lane j of its own row (v_fmac_f64_dpp row_newbcast:j).  As M broadcast reads per thread the step kept the
+        // LDS pipe busy ~300 cycles (6 waves x (M / 2 + 1) ds_read2_b64, each a full 64-lane transfer): the per-step stamps showed 600
+        // cycles between the barrier and the data
         double inv = dn[s];
-        double u[M];
-#pragma unroll
-        for (int j = 0; j < M; ++j) u[j] = U[(s & 1) * US + j];
-        asm volatile("" : "+v"(inv));
-#pragma unroll
-        for (int j = 0; j < M; ++j) asm volatile("" : "+v"(u[j]));
+        double uvec = U[(s & 1) * US + (tid & 15)];
         // leave-one-out veto: T_js^2 >= d / piv_eps  (inv = 1/d; negative for a leaving pivot, 0 for a rejected one); the rhs row is no variable
         if (var_row && (pv[s] * pv[s]) * (inv * piv_eps) >= 1.0) veto = veto < s ? veto : s;
-        if (__builtin_amdgcn_readfirstlane(__double2hiint(inv)) & 0x7ff00000) {
-            const double ainv = fabs(inv), fz = -pv[s] * inv;
-            if (myj == s) {
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(__double2hiint(inv)) & 0x7ff00000, 1)) {
+            const bool piv = myj == s;
+            const double ainv = fabs(inv);
+            double mult = piv ? ainv : -pv[s] * inv;         // pivot row: u |1/d| = fma(|1/d|, u, 0);  other rows: fma(-z / d, u, own entry)
+            const double ps = piv ? -inv : pv[s] * ainv;
+            asm volatile("s_nop 1" : "+v"(mult), "+v"(uvec));   // (a DPP read of a fresh VALU result needs two wait states the assembler cannot see)
 #pragma unroll
-                for (int j = 0; j < M; ++j) pv[j] = (j == s) ? -inv : u[j] * ainv;
-            } else {
-#pragma unroll
-                for (int j = 0; j < M; ++j) pv[j] = (j == s) ? pv[s] * ainv : fma(fz, u[j], pv[j]);
+            for (int j = 0; j < M; ++j) {
+                if (j == s) continue;
+                double acc = piv ? 0.0 : pv[j];
+                lz_fmac_bcast(acc, uvec, mult, j);
+                pv[j] = acc;
             }
+            pv[s] = ps;
         }
     }
-    return veto;
+    LZ_PSTAMP(9);
+    if (veto < M) atomicMin(vflag, veto);
+    __syncthreads();
+    LZ_PSTAMP(11);
+    const int vs = __builtin_amdgcn_readfirstlane(*vflag);
+    if (vs >= M && has_row) {                                // no step refused: the final panel = rows / columns of the pivoted variables
+#pragma unroll
+        for (int j = 0; j < M; ++j) Pn[(size_t)j * ld + tid] = pv[j];
+    }
+    return vs;
 }
 
-// the block's panel through lz_panel_steps: redo on a veto, write the final panel back, flip the basis flags of the accepted pivots;
-// returns the number of accepted pivots
+// the block's panel through lz_panel_steps: redo on a veto (the panel image is untouched until no step is refused), flip the basis flags
+// of the accepted pivots; returns the number of accepted pivots
 template <int NT>
 __device__ __forceinline__ int lz_panel_stepwise(double *__restrict__ Pn, double *__restrict__ Zn, double *__restrict__ dn, double *__restrict__ U,
                                                  int *__restrict__ vflag, int m_, int ld_, uint8_t *__restrict__ s_basic, int myj, double piv_eps,
-                                                 int tid, unsigned long long &nveto)
+                                                 int tid, unsigned long long &nveto, unsigned long long *stk = nullptr)
 {
+#ifdef PARTLS_LZ_STAMPS
+    unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
     const int m = __builtin_amdgcn_readfirstlane(m_), ld = __builtin_amdgcn_readfirstlane(ld_);
     const bool has_row = tid < ld, var_row = tid < ld - 1;
     const bool idle_wave = __builtin_amdgcn_readfirstlane((tid & ~63) >= ld ? 1 : 0) != 0;
     const bool my_basic = myj >= 0 && s_basic[tid] != 0;
     const int lane = tid & 63;
     unsigned skip = 0;
-    double pv[GJ_MB];
     for (;;) {
         if (tid == 0) *vflag = GJ_MB;
-        // (the barrier of the first step orders this store before every atomicMin below: a veto is only raised after step 0's barrier)
-        int veto;
+        // (the barrier of the first step orders this store before every atomicMin: a veto is only raised after step 0's barrier)
+        int vs;
         switch (m) {
-#define LZ_PS(i) case i: veto = lz_panel_steps<i>(Pn, Zn, U, dn, ld, myj, my_basic, skip, piv_eps, tid, has_row, var_row, idle_wave, pv); break;
+#define LZ_PS(i) case i: vs = lz_panel_steps<i>(Pn, Zn, U, dn, vflag, ld, myj, my_basic, skip, piv_eps, tid, has_row, var_row, idle_wave, stk); break;
             LZ_PS(1) LZ_PS(2) LZ_PS(3) LZ_PS(4) LZ_PS(5) LZ_PS(6) LZ_PS(7) LZ_PS(8) LZ_PS(9) LZ_PS(10) LZ_PS(11) LZ_PS(12) LZ_PS(13) LZ_PS(14) LZ_PS(15)
 #undef LZ_PS
-            default: veto = lz_panel_steps<GJ_MB>(Pn, Zn, U, dn, ld, myj, my_basic, skip, piv_eps, tid, has_row, var_row, idle_wave, pv); break;
+            default: vs = lz_panel_steps<GJ_MB>(Pn, Zn, U, dn, vflag, ld, myj, my_basic, skip, piv_eps, tid, has_row, var_row, idle_wave, stk); break;
         }
-        if (veto < m) atomicMin(vflag, veto);
-        __syncthreads();
-        const int vs = __builtin_amdgcn_readfirstlane(*vflag);
+        LZ_PSTAMP(10);                                        // (entry, the whole variant)
         if (vs >= m) break;
         skip |= 1u << vs;                                     // the first refused step changes every later one: one at a time
         ++nveto;
         __syncthreads();                                      // everybody has read the flag before thread 0 resets it
     }
-    // the final panel: rows / columns of the pivoted variables (the panel image was not touched until here)
-    if (has_row && !idle_wave) {
-#pragma unroll
-        for (int j = 0; j < GJ_MB; ++j) if (j < m) Pn[(size_t)j * ld + tid] = pv[j];
-    }
     const double dmy = dn[lane < m ? lane : 0];
     const unsigned accm = (unsigned)__ballot(lane < m && dmy != 0.0);
     if (myj >= 0 && dn[myj] != 0.0) s_basic[tid] ^= 1;         // accepted pivots change sides
+    LZ_PSTAMP(12);
     __syncthreads();
+    LZ_PSTAMP(13);
     return __popc(accm);
 }
 
@@ -631,7 +651,7 @@ __global__ __launch_bounds__(NT) void sweep_lazy_kernel(SweepParams p, int mb, i
                         // one barrier per step, the register kernel's panel: 2-4 % ahead of the two-phase form on the 512-thread plan (D = 340:
                         // 4.64 -> 4.74 M solves/s, D = 500: 608 -> 634 k), and no polled progress word; on the 1024-thread plan a barrier
                         // meets 16 waves and the form is 2x slower (D = 600: 12.5 -> 26.9 ms per 4096 patterns): there the two-phase form stays
-                        acc_piv = lz_panel_stepwise<NT>(Pn, Zn, dn, tab, reinterpret_cast<int *>(red), m, ld, s_basic, myj, p.piv_eps, tid, nveto);
+                        acc_piv = lz_panel_stepwise<NT>(Pn, Zn, dn, tab, reinterpret_cast<int *>(red), m, ld, s_basic, myj, p.piv_eps, tid, nveto, LZ_STK);
                         (void)lz_fault; (void)basm;
                     } else if constexpr (NT <= 512) {
                         acc_piv = m <= 8 ? lz_panel_eliminate<NT, 8>(Pn, Zn, dn, tab, red, ks, m, ld, s_basic, myj, basm, p.piv_eps, tid, nveto, LZ_STK, lz_fault)
