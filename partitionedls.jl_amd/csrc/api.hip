@@ -220,7 +220,7 @@ partls_status ctx_prepare(partls_ctx *c, const double *X, int64_t N, int64_t M, 
     t_begin(c, PARTLS_T_PREP);
     PARTLS_HIP_CHECK(launch_prep(c->G.as<double>(), c->ldg, (int)M, eta, c->maskAugD.as<uint64_t>(), faithful ? 0 : 1,
                                  c->permP, c->scale.as<double>(), c->Tfull.as<double>(), c->n, c->stream));
-    c->use_reg = sweep_reg_supported(c->n) && !(flags & PARTLS_OPT_GENERIC_KERNEL);
+    c->use_reg = sweep_reg_supported(c->n) && c->n <= 16 * c->knobs.reg_maxt && !(flags & PARTLS_OPT_GENERIC_KERNEL);
     if (c->use_reg) {
         c->T = sweep_reg_tiles(c->n);
         PARTLS_HIP_CHECK(c->T0reg.ensure(sweep_reg_t0_doubles(c->T) * sizeof(double)));
@@ -873,6 +873,7 @@ try {
     c->knobs.no_coop = getenv("PARTLS_NO_COOP") != nullptr;
     c->knobs.no_export = getenv("PARTLS_NO_EXPORT") != nullptr;
     c->knobs.no_staged_upload = getenv("PARTLS_NO_STAGED_UPLOAD") != nullptr;
+    if (const char *e = getenv("PARTLS_REG_MAXT")) { const int v = atoi(e); if (v >= 1 && v <= 20) c->knobs.reg_maxt = v; }
     c->knobs.eager_generic = getenv("PARTLS_EAGER_GENERIC") != nullptr;
     c->knobs.bnb_cold = getenv("PARTLS_BNB_COLD") != nullptr;
     if (const char *e = getenv("PARTLS_BNB_BATCH")) c->knobs.bnb_batch = atoi(e);

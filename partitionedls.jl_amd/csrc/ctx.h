@@ -56,6 +56,9 @@ struct partls_knobs {
     int gram_S = 0, gram_cr = 0; // PARTLS_GRAM_S / PARTLS_GRAM_CR: Gram work decomposition overrides
     int coop_rows = 0;           // PARTLS_COOP_ROWS: tableau rows per workgroup of the cooperative kernel (0 = automatic)
     bool no_coop = false;        // PARTLS_NO_COOP: single large solves on the one-workgroup kernel
+    int reg_maxt = 18;           // PARTLS_REG_MAXT (1..20): tile columns up to which the register kernel runs (n <= 16 x this).  Its T = 19 / 20
+                                 // instantiations spill 120-600 VGPRs and lose to the deferred-update kernel since round 4 (65 536 patterns: D = 304
+                                 // 5.5 against 6.3 M solves/s, D = 320 2.3 against 6.1 M; BnB nodes 1.03 / 1.01 against 1.12 / 1.01 M per second)
     bool no_staged_upload = false; // PARTLS_NO_STAGED_UPLOAD: host X goes up with one pageable hipMemcpy2DAsync, as through round 3 (A/B tests)
     bool no_export = false;      // PARTLS_NO_EXPORT: the winner is always solved again from the empty basis (A/B tests)
     bool eager_generic = false;  // PARTLS_EAGER_GENERIC: n > 320 on sweep_generic.hip (every block applied to the whole tableau) instead of sweep_lazy.hip (A/B tests)

@@ -41,7 +41,7 @@ namespace partls {
 namespace blk {
 
 static constexpr int THREADS = 512;
-static constexpr int MAXT = 20;                 // n <= 320 (T = 21 already runs no faster than the global-memory kernel: 1500 spilled VGPRs)
+static constexpr int MAXT = 20;                 // n <= 320 compiled (T = 21: 1500 spilled VGPRs); the library switches to sweep_lazy.hip beyond T = 18 (ctx.h: reg_maxt)
 #ifndef PARTLS_UPD_UNROLL
 #define PARTLS_UPD_UNROLL 1
 #endif

@@ -173,3 +173,36 @@ def test_fuzz_large_n_generic_path_vs_oracle(partls, oracle, D):
     np.testing.assert_allclose(got, ref["all_opt"], rtol=1e-8, atol=1e-8)
     m2, _, r2 = partls.fit(partls.Opt, X, y, P)
     assert abs(r2.opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+
+
+@pytest.mark.parametrize("D", [300, 305, 319])
+def test_top_of_the_register_kernel_behind_its_knob(partls, oracle, D):
+    """Since round 4 the library leaves the register kernel at T = 18 tile columns (n <= 288): its T = 19 / 20 instantiations spill and lose
+    to the deferred-update kernel.  They stay compiled behind PARTLS_REG_MAXT (read at context creation): the same problem on both
+    kernels, every pattern against the oracle, and the two kernels against each other."""
+    import os
+    rng = np.random.default_rng(9900 + D)
+    K = 3
+    N = 2 * D + 11
+    P = np.zeros((D, K), dtype=np.int64)
+    P[np.arange(D), rng.integers(0, K, size=D)] = 1
+    X = rng.standard_normal((N, D))
+    y = X @ (rng.random(D) * np.array([2.0, -1.0, 0.5])[P.argmax(1)]) + 0.7 + 0.1 * rng.standard_normal(N)
+    ref = oracle.fit_opt(X, y, P, return_all=True)
+    got = {}
+    for maxt in ("18", "20"):
+        os.environ["PARTLS_REG_MAXT"] = maxt
+        try:
+            ctx = partls.Context()
+        finally:
+            os.environ.pop("PARTLS_REG_MAXT", None)
+        ctx.opt_prepare(X, y, P, 0.0, partls.lowlevel.OPT_FAITHFUL_INTERCEPT)
+        bo, bp, all_opt, unconv = ctx.opt_sweep(0, -1, want_all=True)
+        assert unconv == 0
+        got[maxt] = (all_opt.copy(), ctx.opt_finish(bp))
+        ctx.close()
+    for maxt in ("18", "20"):
+        np.testing.assert_allclose(got[maxt][0], ref["all_opt"], rtol=1e-8, atol=1e-8)
+        assert abs(got[maxt][1][3] - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(got["18"][0], got["20"][0], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(got["18"][1][0], got["20"][1][0], atol=1e-8)
