@@ -187,7 +187,8 @@ partls_status partls_bnb_leaf(partls_ctx *ctx, uint64_t pat, uint64_t free_group
                               double *alpha, double *beta, double *t, double *opt);
 /* Node bounds with tableau SNAPSHOTS, for a host that runs the search itself and shards it over GPUs (dist.py deals every node to the
  * rank that holds its parent's snapshot): node i starts from the final tableau stored in src_slot[i] (-1: the fresh tableau) and leaves
- * its own in dst_slot[i] (out; -1: pool full, no free group left, or n > 320).  The host keeps the reference counts and returns slots
+ * its own in dst_slot[i] (out; -1: pool full, no free group left, or the PARTLS_EAGER_GENERIC test kernel; both production kernels take
+ * snapshots, at any n <= 1023).  The host keeps the reference counts and returns slots
  * with partls_bnb_snap_release; partls_bnb_snap_begin (after every prepare, before the first bound) empties the pool. */
 partls_status partls_bnb_snap_begin(partls_ctx *ctx);
 partls_status partls_bnb_bound_snap(partls_ctx *ctx, int64_t count, const uint64_t *pat, const uint64_t *free_groups,
