@@ -206,10 +206,11 @@ def main():
             # Beyond the register kernel the tableau lives in global memory (sweep_lazy.hip): the bound that binds is HBM.  Bytes per
             # sweep launch from the round's rocprofv3 FETCH_SIZE / WRITE_SIZE passes of the same problem (tools/profile_r03.sh).
             lz_traffic, lz_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_d340_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r04_d340_traffic.json")
+            if not os.path.exists(tpath): tpath = os.path.join(ROOT, "profiles", "r03_d340_traffic.json")
             if world == 1 and args.config == "L340" and not args.faithful and os.path.exists(tpath):
                 lz_traffic = json.load(open(tpath))["deferred_update_kernel"].get("hbm_bytes_per_sweep")
-                lz_src = "offline PMC (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel on this problem), profiles/r03_d340_traffic.json — not measured in this run"
+                lz_src = "offline PMC (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of this kernel on this problem), profiles/" + os.path.basename(tpath) + " — not measured in this run"
             pass_flops = res["pivots"] * float(n_tab) * n_tab          # every pivot: one rank-1 update of the triangle, n^2/2 entries x 2 flop
             out["roofline"] = {"bound": "hbm", "achieved": None if lz_traffic is None else lz_traffic / sweep_avg_s / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": None if lz_traffic is None else lz_traffic / sweep_avg_s / 1e9 / HBM_PEAK_GBS,

@@ -63,6 +63,19 @@ for k, v in g.items():
                         "executed_flops_per_dispatch": v["SQ_INSTS_VALU_MFMA_F64"] / n * 2048}
 json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES -- python3 tools/gram_bench.py 1000000 512 16 3",
            "kernels": g}, open(os.path.join(S, "r04_c4_gram_pmc.json"), "w"), indent=1)
+# beyond the register kernel: the deferred-update kernel's traffic per 2^18-pattern sweep (the script sweeps twice; the short calibration launch is its own instantiation)
+ls = kernel_stats("l340_stats", "r04_d340_lazy_kernel_stats.csv")
+lf, lw = counters("l340_fetch", "sweep_lazy_kernel<512, false>"), counters("l340_write", "sweep_lazy_kernel<512, false>")
+if lf and lw:
+    fk_ = sum(v.get("FETCH_SIZE", 0) for v in lf.values()); wk_ = sum(v.get("WRITE_SIZE", 0) for v in lw.values())
+    n_ = max(v.get("dispatches", 1) for v in lf.values())
+    avg = None
+    for r in ls or []:
+        if "sweep_lazy_kernel<512, false>" in r.get("Name", ""): avg = float(r["AverageNs"]) / 1e6
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/generic_timing.py 20000 340 18  (D = 340, K = 18: 2^18 patterns; "
+                          "tools/profile_r04.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM)",
+               "deferred_update_kernel": {"fetch_size_kib": fk_, "write_size_kib": wk_, "dispatches": n_, "hbm_bytes_per_sweep": (2 * fk_ + wk_) * 1024 / n_, "avg_ms": avg}},
+              open(os.path.join(S, "r04_d340_traffic.json"), "w"), indent=1)
 import shutil
 for c in ("c2", "c3", "c4", "c5", "l340"):
     f = os.path.join(O, f"bench_{c}.json")

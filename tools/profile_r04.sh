@@ -21,6 +21,14 @@ echo c4 done
 # C5: the 2^24-pattern enumeration + the BnB search with warm-started node bounds (bnb_hard leg: 170k nodes, twice + the 2^24 certification sweep)
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats -- python3 bench.py --config C5 --steps 1 --warmup 0 --no-cpu-baseline > $O/c5_stats.log 2>&1 || exit 1
 echo c5 done
+# beyond the register kernel (D = 340, K = 18: sweep_lazy.hip): kernel time and HBM traffic of the 2^18-pattern sweep (two launches per run)
+L="python3 tools/generic_timing.py 20000 340 18"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/l340_stats -- $L > $O/l340_stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/l340_fetch -- $L > $O/l340_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/l340_write -- $L > $O/l340_write.log 2>&1 || exit 1
+echo l340 done
+# (the L340 bench line below takes its bytes per sweep from profiles/r04_d340_traffic.json: condense the passes above first)
+python3 tools/collect_r04.py $O > /dev/null && cp $O/summary/r04_d340_traffic.json profiles/ || exit 1
 # plain bench lines of every config (no profiler attached)
 python3 bench.py --config C2 --steps 50 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err || exit 1
 python3 bench.py --config C3 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1
