@@ -243,3 +243,27 @@ def test_bnb_search_warm_through_the_snapshot_abi(partls, oracle):
     assert abs(mu - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"]) and abs(mu - mu_lib) <= 1e-12 * mu_lib and abs(mu - cold[0]) <= 1e-10 * mu
     assert (pat, free) == (pat_lib, free_lib) and n == n_lib and n > 20
     assert abs(opt - ref["opt"]) <= 1e-9 * max(1.0, ref["opt"])
+
+
+@pytest.mark.parametrize("D", [290, 312])
+def test_alt_bnb_and_opt_between_the_two_sweep_kernels(partls, oracle, D):
+    """n = 291 / 313: since round 4 (second half) these sizes run on the deferred-update kernel and, for single solves, on the cooperative
+    kernel — no longer on the register kernel's spilling T = 19 / 20 instantiations.  Alt, Opt and a BnB search that branches (snapshots
+    of the deferred-update kernel) against the dense oracle."""
+    X, y, P, _ = oracle.synth(20260160 + D, 1200, D, 4)
+    rng = np.random.default_rng(D)
+    a0 = rng.random(D + 1); b0 = (rng.random(5) - 0.5) * 10
+    ref = oracle.fit_alt(X, y, P, a0, b0)
+    m, _, rep = partls.fit(partls.Alt, X, y, P, alpha0=a0, beta0=b0)
+    assert abs(rep.opt - ref["opt"]) <= 1e-8 * max(1.0, ref["opt"])
+    np.testing.assert_allclose(m.α, ref["alpha"], atol=1e-6)
+    ro = oracle.fit_opt(X, y, P)
+    mo, _, repo = partls.fit(partls.Opt, X, y, P)
+    assert abs(repo.opt - ro["opt"]) <= 1e-9 * max(1.0, ro["opt"])
+    np.testing.assert_allclose(mo.α, ro["alpha"], atol=1e-7)
+    yn = 1.0 + 0.3 * np.random.default_rng(D + 1).standard_normal(X.shape[0])       # a target nobody explains: the search has to branch
+    rb = oracle.fit_bnb(X, yn, P)
+    mb, _, repb = partls.fit(partls.BnB, X, yn, P)
+    assert abs(repb.opt - rb["opt"]) <= 1e-8 * max(1.0, rb["opt"])
+    mo2, _, repo2 = partls.fit(partls.Opt, X, yn, P)
+    assert abs(repb.opt - repo2.opt) <= 1e-8 * max(1.0, repo2.opt)
