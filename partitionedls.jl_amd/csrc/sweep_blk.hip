@@ -55,11 +55,6 @@ static constexpr int MB = 8;                    // pivots per block (a tile colu
 static constexpr int EXPORT_MAXT = 17;          // ... up to this tile count (beyond it the two live registers of the export start spilling: 22 -> 32 spilled VGPRs at T = 18)
 static constexpr int MBB = PARTLS_MB_BIG;       // ... of the 512-thread kernel (8..16; experiments: tools/experiments/README.md)
 static constexpr int NO_VETO = 99;
-#ifndef PARTLS_PANEL_DPP
-#define PARTLS_PANEL_DPP 0                      // 1: the panel's row update takes the pivot rows' entries by DPP row broadcasts — the form that gained 6 % in
-                                                // sweep_lazy.hip's copy of this panel (6 row waves, blocks of up to 15 pivots) and LOSES 2 % here (C3 sweep 49.6 against
-                                                // 48.6 ms; with the pivot row fixed up from scalar registers instead of per-lane selects: 51.8): tools/experiments/README.md
-#endif
 
 constexpr int nslots(int T) { return T * (T + 1) / 2; }
 constexpr int tri(int g) { return g * (g + 1) / 2; }
@@ -92,18 +87,6 @@ template <class PT> __device__ __forceinline__ PT *uniform_ptr(PT *p)     // a w
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
     return (PT *)(((unsigned long long)hi << 32) | lo);
-}
-// acc += y[lane 16 (lane / 16) + g] * x   (v_fmac_f64_dpp row_newbcast, gfx90a+; semantics and rate checked by tools/ubench/fmac_dpp.hip);
-// g is a constant after unrolling: the switch folds to the one instruction
-__device__ __forceinline__ void fmac_bcast(double &acc, double y, double x, int g)
-{
-    switch (g) {
-#define PARTLS_FB(G) case G: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #G " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(y), "v"(x)); break;
-        PARTLS_FB(0) PARTLS_FB(1) PARTLS_FB(2) PARTLS_FB(3) PARTLS_FB(4) PARTLS_FB(5) PARTLS_FB(6) PARTLS_FB(7) PARTLS_FB(8) PARTLS_FB(9) PARTLS_FB(10)
-        PARTLS_FB(11) PARTLS_FB(12) PARTLS_FB(13) PARTLS_FB(14) PARTLS_FB(15)
-#undef PARTLS_FB
-        default: break;
-    }
 }
 __device__ __forceinline__ int sign_of_var(uint64_t m, uint64_t pat) { return 2 * __popcll(m & pat) - __popcll(m); }
 __device__ __forceinline__ double readlane_f64(double v, int lane)      // lane: wave-uniform
@@ -269,31 +252,6 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
             Dinv[s] = (my_basic || d > piv_eps) ? fast_rcp(d) : 0.0;
         }
         __syncthreads();
-#if PARTLS_PANEL_DPP
-        // ONE LDS read per thread brings the pivot rows' entries of column s: lane l of every row of 16 lanes takes u_l, and the row update reads
-        // u_j from lane j of its own row (v_fmac_f64_dpp row_newbcast:j) — against M broadcast reads per thread, which keep the LDS pipe busy
-        // 5 waves x (M / 2 + 1) x 8 cycles right behind every barrier (round 4, first measured on sweep_lazy.hip's copy of this panel)
-        double inv = Dinv[s];
-        double uvec = U[(s & 1) * US + (tid & 15)];
-        asm volatile("" : "+v"(inv), "+v"(uvec));            // both reads issued right behind the barrier
-        if ((pv[s] * pv[s]) * (inv * piv_eps) >= 1.0) veto = veto < s ? veto : s;
-        if (__builtin_amdgcn_readfirstlane(__double2hiint(inv)) & 0x7ff00000) {
-            // one instruction stream for all rows: the pivot row takes u |1/d| = fma(|1/d|, u, 0), the others fma(-z / d, u, own entry)
-            const bool piv = myj == s;
-            const double ainv = fabs(inv);
-            double mult = piv ? ainv : -pv[s] * inv;
-            const double ps = piv ? -inv : pv[s] * ainv;
-            asm volatile("s_nop 1" : "+v"(mult), "+v"(uvec));   // a DPP read of a fresh VALU result needs two wait states the assembler cannot see
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                if (j == s) continue;
-                double acc = piv ? 0.0 : pv[j];
-                fmac_bcast(acc, uvec, mult, j);
-                pv[j] = acc;
-            }
-            pv[s] = ps;
-        }
-#else
         double inv = Dinv[s];
         double u[M];
 #pragma unroll
@@ -316,7 +274,6 @@ __device__ __forceinline__ int panel_block(double *P, double *Z, double *U, doub
                 for (int j = 0; j < M; ++j) pv[j] = (j == s) ? pv[s] * ainv : fma(fz, u[j], pv[j]);
             }
         }
-#endif
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) P[j * CW + prow] = pv[j];
