@@ -359,9 +359,14 @@ partls_status solve_nodes(partls_ctx *c, const std::vector<int8_t> &codes, size_
         PARTLS_HIP_CHECK(launch_any_sweep(c, p, grid));
     }
     unsigned long long counters[4] = {0, 0, 0, 0};                 // unconverged, pivots, vetoes, (cooperative kernel) blocks
-    PARTLS_HIP_CHECK(c->nodeOut.resize(out_words));
-    const double *outw = c->nodeOut.data();
-    PARTLS_HIP_CHECK(hipMemcpyAsync(c->nodeOut.data(), c->nodeSol.p, out_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // page-locked up to 64 MB (a fit's single solves and node batches: KBs to a few MB); a caller that bounds a million nodes in one cold
+    // batch gets a pageable buffer instead of gigabytes of pinned host memory
+    std::vector<double> outw_big;
+    double *outw_buf;
+    if (out_words <= ((size_t)64 << 20) / sizeof(double)) { PARTLS_HIP_CHECK(c->nodeOut.resize(out_words)); outw_buf = c->nodeOut.data(); }
+    else { outw_big.resize(out_words); outw_buf = outw_big.data(); }
+    const double *outw = outw_buf;
+    PARTLS_HIP_CHECK(hipMemcpyAsync(outw_buf, c->nodeSol.p, out_words * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (dump_reg) {
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hTab, c->nodeTab.p, tabd * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PARTLS_HIP_CHECK(hipMemcpyAsync(c->hBasic, c->nodeBasic.p, (size_t)16 * c->T, hipMemcpyDeviceToHost, c->stream));
